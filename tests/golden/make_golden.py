@@ -1,0 +1,346 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own code.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+Imports the reference's python files unmodified (via refenv + the `ocnn`
+stand-in) and records inputs / expected outputs.  Only data is written: tensors,
+state_dict key names + shapes, sha256 digests.  No reference source is copied.
+"""
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refenv  # noqa: E402
+
+refenv.setup()
+
+import torch  # noqa: E402
+import common as C  # noqa: E402
+
+from models.networks import modules as RM  # noqa: E402
+from models.networks.dualoctree_networks import dual_octree as RD  # noqa: E402
+from models.networks.dualoctree_networks import modules as RVM  # noqa: E402
+from models.networks.diffusion_networks import graph_unet_hr, graph_unet_lr  # noqa: E402
+from models.networks.diffusion_networks.graph_unet_union import UNet3DModel as RUnion  # noqa: E402
+from utils.util_dualoctree import split2octree_small, split2octree_large  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def save(name, obj):
+    path = os.path.join(HERE, name + '.pt')
+    torch.save(obj, path)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+def load_filled(module):
+    ks = [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
+    module.load_state_dict(C.fill_state_dict(ks), strict=True)
+    return ks
+
+
+def octree_record(oc):
+    d = oc.depth
+    return {'depth': d, 'full_depth': oc.full_depth, 'batch_size': oc.batch_size,
+            'nnum': oc.nnum.clone(), 'nnum_nempty': oc.nnum_nempty.clone(),
+            'keys': [k.clone() if k is not None else None for k in oc.keys[:d + 1]],
+            'children': [c.clone() if c is not None else None for c in oc.children[:d + 1]]}
+
+
+def canon(edge_idx, edge_dir):
+    row, col = edge_idx[0], edge_idx[1]
+    n = int(max(int(row.max()), int(col.max())) + 1)
+    order = torch.argsort((row * 7 + edge_dir) * n + col, stable=True)
+    return torch.stack([row[order], col[order]]), edge_dir[order]
+
+
+def doctree_record(doc, full=True):
+    rec = {'nnum': doc.nnum.clone(), 'lnum': doc.lnum.clone(), 'ncum': doc.ncum.clone(),
+           'total_num': doc.total_num, 'depth': doc.depth, 'full_depth': doc.full_depth,
+           'batch_size': doc.batch_size, 'graph': {}}
+    for d in range(doc.full_depth, doc.depth + 1):
+        g = doc.graph[d]
+        ei, ed = canon(g['edge_idx'], g['edge_dir'])
+        r = {'E': int(ed.numel()), 'N': int(g['node_type'].numel()),
+             'sha_edge_idx': C.sha_int(ei), 'sha_edge_dir': C.sha_int(ed),
+             'sha_node_type': C.sha_int(g['node_type']), 'sha_keyd': C.sha_int(g['keyd']),
+             'sha_node_mask': C.sha_int(g['node_mask']), 'sha_batch_id': C.sha_int(doc.batch_id(d)),
+             'sorted_ok': bool((torch.diff(g['edge_idx'][0] * 7 + g['edge_dir']) >= 0).all())}
+        if full:
+            r.update(edge_idx=ei.to(torch.int32), edge_dir=ed.to(torch.int8),
+                     node_type=g['node_type'].to(torch.int8), keyd=g['keyd'].clone(),
+                     node_mask=g['node_mask'].clone(), batch_id=doc.batch_id(d).to(torch.int16))
+        rec['graph'][d] = r
+    return rec
+
+
+def tiny_doctree(B=2, seed=3):
+    split = C.random_split_small(B, 2, seed)
+    oc = split2octree_small(split, 4, 2)
+    doc = RD.DualOctree(oc)
+    doc.post_processing_for_docnn()
+    return split, oc, doc
+
+
+def small_doctree(B=2, seed=4):
+    """full_depth 3 / depth 5 tree for the whole-network goldens (better conditioned than 4^3)."""
+    split = C.random_split_small(B, 3, seed)
+    oc = split2octree_small(split, 5, 3)
+    doc = RD.DualOctree(oc)
+    doc.post_processing_for_docnn()
+    return split, oc, doc
+
+
+# ---------------------------------------------------------------- G2 / G3
+def g_octree_graph():
+    split, oc, doc = tiny_doctree()
+    out = {'tiny': {'split_small': split, 'octree': octree_record(oc), 'doctree': doctree_record(doc)}}
+    # depth-6 -> depth-8 growth on the tiny tree too (full_depth 2 -> 4 -> 6)
+    x, y, z, b = oc.xyzb(4)
+    sl = C.random_split_large(int(oc.nnum[4]), 11)
+    oc_l = split2octree_large(oc, sl, 4)
+    doc_l = RD.DualOctree(oc_l)
+    doc_l.post_processing_for_docnn()
+    out['tiny_large'] = {'split_large': sl, 'octree': octree_record(oc_l),
+                         'doctree': doctree_record(doc_l, full=False)}
+    # config-shaped: shell-6, B=2 (jittered), and shell-8 B=1 as digests
+    sp = C.shell6_split(2, jitter=True)
+    oc6 = split2octree_small(sp, 6, 4)
+    doc6 = RD.DualOctree(oc6)
+    doc6.post_processing_for_docnn()
+    rec6 = octree_record(oc6)
+    out['shell6_b2'] = {'octree_nnum': rec6['nnum'], 'octree_nnum_nempty': rec6['nnum_nempty'],
+                        'sha_keys': [C.sha_int(k) for k in rec6['keys']],
+                        'sha_children': [C.sha_int(c) for c in rec6['children']],
+                        'doctree': doctree_record(doc6, full=False)}
+    sp1 = C.shell6_split(1)
+    oc61 = split2octree_small(sp1, 6, 4)
+    x, y, z, b = oc61.xyzb(6)
+    sl8 = C.shell8_split_large(x, y, z)
+    oc8 = split2octree_large(oc61, sl8, 6)
+    doc8 = RD.DualOctree(oc8)
+    doc8.post_processing_for_docnn()
+    rec8 = octree_record(oc8)
+    out['shell8_b1'] = {'octree_nnum': rec8['nnum'], 'octree_nnum_nempty': rec8['nnum_nempty'],
+                        'sha_keys': [C.sha_int(k) for k in rec8['keys']],
+                        'sha_children': [C.sha_int(c) for c in rec8['children']],
+                        'doctree': doctree_record(doc8, full=False)}
+    save('g_octree_graph', out)
+
+
+# ---------------------------------------------------------------- G4
+def g_modules():
+    split, oc, doc = tiny_doctree()
+    out = {'split_small': split}
+    g = torch.Generator().manual_seed(5)
+    N4 = doc.graph[4]['node_type'].numel()
+    N3 = doc.graph[3]['node_type'].numel()
+
+    def rnd(name, *s):
+        return C.rand_input(name, *s)
+
+    # scatter_mean
+    from models.networks.diffusion_networks.utils.scatter import scatter_mean
+    src = rnd('sm', 50, 6)
+    idx = torch.randint(0, 9, (50,), generator=g)
+    out['scatter_mean'] = {'index': idx, 'dim_size': 12,
+                           'out': scatter_mean(src, idx, dim=0, dim_size=12)}
+    # GraphConv
+    for name, cin, cout, nt, bias, d in [('gc_nt0', 5, 7, 0, False, 4), ('gc_nt3_bias', 6, 9, 3, True, 4),
+                                         ('gc_d3', 16, 12, 2, False, 3), ('gc_c64', 64, 40, 3, True, 3)]:
+        m = RM.GraphConv(cin, cout, 7, 7, nt, use_bias=bias)
+        ks = load_filled(m)
+        x = rnd(name, doc.graph[d]['node_type'].numel(), cin)
+        out[name] = {'d': d, 'args': (cin, cout, 7, 7, nt, bias), 'keys': ks, 'out': m(x, doc, d)}
+    # DualOctreeGroupNorm
+    for name, c in [('gn12', 12), ('gn64', 64), ('gn60', 60), ('gn96', 96)]:
+        m = RM.DualOctreeGroupNorm(c)
+        ks = load_filled(m)
+        x = rnd(name, N4, c) * 2 + 0.5
+        out[name] = {'d': 4, 'c': c, 'group': m.group, 'keys': ks,
+                     'out': m(data=x, doctree=doc, depth=4)}
+    # Downsample / Upsample
+    m = RM.Downsample(6)
+    ks = load_filled(m)
+    x = rnd('down', 8 * 5, 6)
+    out['down'] = {'keys': ks, 'out': m(x)}
+    m = RM.Upsample(6)
+    ks = load_filled(m)
+    x = rnd('up', 5, 6)
+    out['up'] = {'keys': ks, 'out': m(x)}
+    # GraphDownsample / GraphUpsample (U-Net flavour)
+    m = RM.GraphDownsample(8, 10, 7, 7, 2)
+    ks = load_filled(m)
+    x = rnd('gdown', N4, 8)
+    out['gdown'] = {'d': 4, 'args': (8, 10, 7, 7, 2), 'keys': ks, 'out': m(x, doc, 4)}
+    m = RM.GraphUpsample(8, 10, 7, 7, 3)
+    ks = load_filled(m)
+    x = rnd('gup', N3, 8)
+    out['gup'] = {'d': 3, 'args': (8, 10, 7, 7, 3), 'keys': ks, 'out': m(x, doc, 3)}
+    # VAE flavour
+    for name, cin, cout in [('vdown_same', 8, None), ('vdown_diff', 8, 12)]:
+        m = RVM.GraphDownsample(cin, cout)
+        ks = load_filled(m)
+        x = rnd(name, N4, cin)
+        lm = doc.node_child(3) < 0
+        out[name] = {'args': (cin, cout), 'keys': ks,
+                     'out': m(x, doc, 3, lm, int(doc.nnum[4]), int(doc.lnum[3]))}
+    for name, cin, cout in [('vup_same', 8, None), ('vup_diff', 8, 12)]:
+        m = RVM.GraphUpsample(cin, cout)
+        ks = load_filled(m)
+        x = rnd(name, N3, cin)
+        lm = doc.node_child(3) < 0
+        out[name] = {'args': (cin, cout), 'keys': ks,
+                     'out': m(x, doc, 4, lm, int(doc.nnum[3]))}
+    # GraphResBlockEmbed (B=2, Cin != Cout and Cin == Cout)
+    for name, cin, cout in [('rbe_diff', 16, 24), ('rbe_same', 16, None)]:
+        m = RM.GraphResBlockEmbed(cin, 32, 0.0, cout, 7, 7, 3)
+        ks = load_filled(m)
+        x = rnd(name, N4, cin)
+        emb = rnd(name + 'e', 2, 32)
+        out[name] = {'d': 4, 'args': (cin, 32, 0.0, cout, 7, 7, 3), 'keys': ks,
+                     'out': m(x, emb, doc, 4)}
+    # GraphResBlocks (VAE)
+    m = RM.GraphResBlocks(8, 12, 0.0, 2, 7, 7, 3)
+    ks = load_filled(m)
+    x = rnd('resblocks', N4, 8)
+    out['resblocks'] = {'d': 4, 'args': (8, 12, 0.0, 2, 7, 7, 3), 'keys': ks,
+                        'out': m(x, doc, 4)}
+    # Conv1x1GnGeluSequential
+    m = RM.Conv1x1GnGeluSequential(8, 32)
+    ks = load_filled(m)
+    x = rnd('c1x1gngelu', N4, 8)
+    out['c1x1gngelu'] = {'d': 4, 'keys': ks, 'out': m((x, doc, 4))}
+    save('g_modules', out)
+
+
+# ---------------------------------------------------------------- G5
+def g_dense():
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    m = RM.AttentionBlock(32, num_heads=4)
+    ks = load_filled(m)
+    x = torch.randn(2, 32, 4, 4, 4, generator=g)
+    out['attn'] = {'x': x, 'keys': ks, 'out': m(x)}
+    m = RM.AttentionBlock(128, num_heads=4)
+    ks = load_filled(m)
+    x = torch.randn(1, 128, 8, 8, 8, generator=g)
+    out['attn512'] = {'x': x, 'keys': ks, 'out': m(x)}
+    m = RM.ResnetBlock(3, 8, 12, emb_dim=16, dropout=0.0, use_text_condition=False)
+    ks = load_filled(m)
+    x = torch.randn(2, 8, 4, 4, 4, generator=g)
+    emb = torch.randn(2, 16, generator=g)
+    out['resnet'] = {'x': x, 'emb': emb, 'keys': ks, 'out': m(x, emb)}
+    # lr net (shrunken), stand-alone and as-middle on the tiny doctree
+    split, oc, doc = small_doctree()
+    lr = graph_unet_lr.UNet3DModel(**C.TINY_LR_CFG)
+    ks = load_filled(lr)
+    x = torch.randn(2, 8, 8, 8, 8, generator=g)
+    sc = torch.randn(2, 8, 8, 8, 8, generator=g)
+    t = torch.tensor([0.3, -1.2])
+    out['lr'] = {'x': x, 'x_self_cond': sc, 't': t, 'keys': ks,
+                 'out': lr(x=x, timesteps=t, x_self_cond=sc),
+                 'out_nosc': lr(x=x, timesteps=t)}
+    h = torch.randn(int(doc.nnum[3]), 16, generator=g)
+    out['lr_mid'] = {'h': h, 't': t, 'out': lr.forward_as_middle(h, doc, t, None, None)}
+    out['split_small'] = split
+    save('g_dense', out)
+
+
+# ---------------------------------------------------------------- G6
+def union_cfg(num_classes=None):
+    h, l = C.TINY_HR_CFG, C.TINY_LR_CFG
+    cfg = dict(stage_flag='hr', image_size=[8, 32], input_depth=[3, 5], unet_type=['lr', 'hr'],
+               full_depth=3, input_channels=[8, 3], out_channels=[8, 3],
+               model_channels=[l['model_channels'], h['model_channels']],
+               num_res_blocks=[[1, 1, 1], h['num_res_blocks']], attention_resolutions=[2, 4],
+               channel_mult=[l['channel_mult'], h['channel_mult']], num_heads=4,
+               use_checkpoint=False, dims=3)
+    if num_classes is not None:
+        cfg['num_classes'] = num_classes
+    return cfg
+
+
+def g_unet():
+    g = torch.Generator().manual_seed(9)
+    split, oc, doc = small_doctree()
+    out = {'split_small': split}
+    for name, ncls in [('uncond', None), ('cond', 5)]:
+        net = RUnion(**union_cfg(ncls)).eval()
+        ks = load_filled(net)
+        x = torch.randn(doc.total_num, 3, generator=g)
+        t = torch.tensor([0.7, 0.7])
+        label = torch.tensor([1, 3]) if ncls else None
+        y = net(unet_type='hr', x=x, doctree=doc, unet_lr=net.unet_lr, timesteps=t,
+                x_self_cond=None, label=label)
+        out[name] = {'x': x, 't': t, 'label': label, 'keys': ks, 'out': y, 'num_classes': ncls}
+    # 3-stage nesting (feature stage nests hr as_middle without lr): fd 2, depths 2/4/6
+    sl = C.random_split_large(int(oc.nnum[5]), 11, p=0.25)
+    oc_l = split2octree_large(oc, sl, 5)
+    doc_l = RD.DualOctree(oc_l)
+    doc_l.post_processing_for_docnn()
+    cfg3 = dict(stage_flag='feature', image_size=[8, 32, 128], input_depth=[3, 5, 7],
+                unet_type=['lr', 'hr', 'feature'], full_depth=3, input_channels=[8, 8, 3],
+                out_channels=[8, 8, 3], model_channels=[16, 32, 32],
+                num_res_blocks=[[1, 1, 1], [1, 1, 0], [1, 1, 1]], attention_resolutions=[2, 4],
+                channel_mult=[[1, 2, 4], [1, 2, 4], [1, 2, 4]], num_heads=4,
+                use_checkpoint=False, dims=3)
+    net = RUnion(**cfg3).eval()
+    ks = load_filled(net)
+    x = torch.randn(doc_l.total_num, 3, generator=g)
+    t = torch.tensor([-0.4, -0.4])
+    y = net(unet_type='feature', x=x, doctree=doc_l, unet_lr=net.unet_hr, timesteps=t,
+            x_self_cond=None, label=None)
+    out['feature'] = {'x': x, 't': t, 'keys': ks, 'out': y, 'split_large': sl, 'cfg': cfg3}
+    save('g_unet', out)
+
+
+# ---------------------------------------------------------------- G7
+def g_sample_loop():
+    from models import octfusion_model_union as OM
+    from models.networks.diffusion_networks.ldm_diffusion_util import beta_linear_log_snr
+    out = {}
+
+    class Fake:
+        pass
+
+    def run(shape, unet_type, df_type, trunc, B, steps, seed):
+        fs = Fake()
+        fs.device = 'cpu'
+        fs.log_snr = beta_linear_log_snr
+        fs.vq_conf = refenv._AttrDict({'data': {'test': {'batch_size': B}}})
+        fs.get_sampling_timesteps = types.MethodType(OM.OctFusionModel.get_sampling_timesteps, fs)
+        A = torch.linspace(-0.5, 0.5, shape[-1] if len(shape) == 2 else shape[1])
+
+        def net(unet_type=None, x=None, doctree=None, timesteps=None, unet_lr=None,
+                x_self_cond=None, label=None):
+            # deterministic fake denoiser: depends on x, the noise level and the self-cond
+            a = A.view(1, -1, *([1] * (x.ndim - 2)))
+            tt = timesteps.view(-1, *([1] * (x.ndim - 1))) if x.ndim > 2 else timesteps[0]
+            y = torch.tanh(x * 0.7 + a) * 0.9 + 0.05 * torch.tanh(tt)
+            if x_self_cond is not None:
+                y = y + 0.1 * x_self_cond
+            return y
+        fs.ema_df = net
+        fs.df = net
+        torch.manual_seed(seed)
+        res = OM.OctFusionModel.sample_loop.__wrapped__(
+            fs, doctree_lr=None, ema=True, shape=shape, ddim_steps=steps, label=None,
+            unet_type=unet_type, unet_lr=None, df_type=df_type, truncated_index=trunc)
+        return res
+
+    out['x0'] = {'shape': (2, 8, 4, 4, 4), 'B': 2, 'steps': 6, 'seed': 123, 'trunc': 0.7,
+                 'out': run((2, 8, 4, 4, 4), 'lr', 'x0', 0.7, 2, 6, 123)}
+    out['eps'] = {'shape': (37, 3), 'B': 2, 'steps': 6, 'seed': 321,
+                  'out': run((37, 3), 'hr', 'eps', 0.0, 2, 6, 321)}
+    out['x0_graph'] = {'shape': (37, 3), 'B': 1, 'steps': 5, 'seed': 77,
+                       'out': run((37, 3), 'hr', 'x0', 0.0, 1, 5, 77)}
+    save('g_sample_loop', out)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['octree_graph', 'modules', 'dense', 'unet', 'sample_loop']
+    for w in which:
+        globals()['g_' + w]()

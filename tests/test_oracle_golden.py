@@ -1,0 +1,239 @@
+"""The CPU oracle against golden vectors captured from the reference's own code
+(tests/golden/make_golden.py).  CPU only."""
+import torch
+import pytest
+
+import common as C
+from oracle import dual_octree as OD
+from oracle import modules as OM
+from oracle import sampler as OS
+from oracle import unet as OU
+from oracle.octree import key2xyz, xyz2key
+
+torch.set_grad_enabled(False)
+TOL = dict(rtol=1e-4, atol=1e-5)
+
+
+def tiny(split):
+    oc = OS.split2octree_small(split, 4, 2)
+    doc = OD.OracleDualOctree(oc)
+    doc.post_processing_for_docnn()
+    return oc, doc
+
+
+def small(split):
+    oc = OS.split2octree_small(split, 5, 3)
+    doc = OD.OracleDualOctree(oc)
+    doc.post_processing_for_docnn()
+    return oc, doc
+
+
+def check_octree(oc, rec):
+    assert oc.depth == rec['depth']
+    assert torch.equal(oc.nnum[:oc.depth + 1], rec['nnum'][:oc.depth + 1])
+    assert torch.equal(oc.nnum_nempty[:oc.depth + 1], rec['nnum_nempty'][:oc.depth + 1])
+    for d in range(oc.depth + 1):
+        assert torch.equal(oc.keys[d], rec['keys'][d])
+        assert torch.equal(oc.children[d].to(torch.int64), rec['children'][d].to(torch.int64))
+
+
+def check_doctree(doc, rec):
+    assert doc.total_num == rec['total_num']
+    assert torch.equal(doc.nnum, rec['nnum']) and torch.equal(doc.lnum, rec['lnum'])
+    assert torch.equal(doc.ncum, rec['ncum'])
+    for d, r in rec['graph'].items():
+        g = doc.graph[d]
+        ei, ed = OD.canonical_edges(g['edge_idx'], g['edge_dir'])
+        assert ed.numel() == r['E'] and g['node_type'].numel() == r['N']
+        assert C.sha_int(ei) == r['sha_edge_idx']
+        assert C.sha_int(ed) == r['sha_edge_dir']
+        assert C.sha_int(g['node_type']) == r['sha_node_type']
+        assert C.sha_int(g['keyd']) == r['sha_keyd']
+        assert C.sha_int(g['node_mask']) == r['sha_node_mask']
+        assert C.sha_int(doc.batch_id(d)) == r['sha_batch_id']
+        if 'edge_idx' in r:
+            assert torch.equal(ei, r['edge_idx'].to(torch.int64))
+            assert torch.equal(ed, r['edge_dir'].to(torch.int64))
+
+
+def test_key_codec_roundtrip():
+    g = torch.Generator().manual_seed(0)
+    x, y, z = (torch.randint(0, 256, (1000,), generator=g) for _ in range(3))
+    b = torch.randint(0, 7, (1000,), generator=g)
+    k = xyz2key(x, y, z, b, depth=8)
+    x2, y2, z2, b2 = key2xyz(k, 8)
+    assert torch.equal(x, x2) and torch.equal(y, y2) and torch.equal(z, z2) and torch.equal(b, b2)
+    # child-octant bit order x->4, y->2, z->1 (dual_octree.py:85-94)
+    assert int(xyz2key(torch.tensor([1]), torch.tensor([0]), torch.tensor([0]), depth=1)) == 4
+    assert int(xyz2key(torch.tensor([0]), torch.tensor([1]), torch.tensor([0]), depth=1)) == 2
+    assert int(xyz2key(torch.tensor([0]), torch.tensor([0]), torch.tensor([1]), depth=1)) == 1
+
+
+def test_octree_and_graph_tiny(golden):
+    G = golden('g_octree_graph')
+    t = G['tiny']
+    oc, doc = tiny(t['split_small'])
+    check_octree(oc, t['octree'])
+    check_doctree(doc, t['doctree'])
+    tl = G['tiny_large']
+    oc_l = OS.split2octree_large(oc, tl['split_large'], 4)
+    check_octree(oc_l, tl['octree'])
+    doc_l = OD.OracleDualOctree(oc_l)
+    doc_l.post_processing_for_docnn()
+    check_doctree(doc_l, tl['doctree'])
+
+
+def test_octree_and_graph_shell(golden):
+    G = golden('g_octree_graph')
+    s6 = G['shell6_b2']
+    oc = OS.split2octree_small(C.shell6_split(2, jitter=True), 6, 4)
+    assert torch.equal(oc.nnum, s6['octree_nnum'])
+    for d in range(7):
+        assert C.sha_int(oc.keys[d]) == s6['sha_keys'][d]
+        assert C.sha_int(oc.children[d]) == s6['sha_children'][d]
+    doc = OD.OracleDualOctree(oc)
+    doc.post_processing_for_docnn()
+    check_doctree(doc, s6['doctree'])
+    # shell-8 (nnum7 = 80320, nnum8 = 402560, N8 = 448232, E8 = 3374048)
+    s8 = G['shell8_b1']
+    oc6 = OS.split2octree_small(C.shell6_split(1), 6, 4)
+    assert oc6.nnum.tolist() == [1, 8, 64, 512, 4096, 4672, 20032]
+    x, y, z, b = oc6.xyzb(6)
+    oc8 = OS.split2octree_large(oc6, C.shell8_split_large(x, y, z), 6)
+    assert torch.equal(oc8.nnum, s8['octree_nnum'])
+    assert int(oc8.nnum[7]) == 80320 and int(oc8.nnum[8]) == 402560
+    doc8 = OD.OracleDualOctree(oc8)
+    doc8.post_processing_for_docnn()
+    check_doctree(doc8, s8['doctree'])
+    assert s8['doctree']['graph'][8]['N'] == 448232 and s8['doctree']['graph'][8]['E'] == 3374048
+
+
+def test_modules(golden):
+    G = golden('g_modules')
+    oc, doc = tiny(G['split_small'])
+    r = G['scatter_mean']
+    torch.testing.assert_close(OM.scatter_mean(C.rand_input('sm', 50, 6), r['index'], r['dim_size']),
+                               r['out'], **TOL)
+    for name in ['gc_nt0', 'gc_nt3_bias', 'gc_d3', 'gc_c64']:
+        r = G[name]
+        sd = C.fill_state_dict(r['keys'])
+        cin, cout, _, _, nt, bias = r['args']
+        x = C.rand_input(name, doc.graph[r['d']]['node_type'].numel(), cin)
+        y = OM.graph_conv(x, doc, r['d'], sd['weights'], sd.get('bias'), nt)
+        torch.testing.assert_close(y, r['out'], **TOL)
+    N4 = doc.graph[4]['node_type'].numel()
+    N3 = doc.graph[3]['node_type'].numel()
+    for name in ['gn12', 'gn64', 'gn60', 'gn96']:
+        r = G[name]
+        sd = C.fill_state_dict(r['keys'])
+        assert OM.gn_groups(r['c']) == r['group']
+        x = C.rand_input(name, N4, r['c']) * 2 + 0.5
+        torch.testing.assert_close(OM.dual_octree_group_norm(x, doc, 4, sd['weights'], sd['bias']),
+                                   r['out'], **TOL)
+    sd = C.fill_state_dict(G['down']['keys'])
+    torch.testing.assert_close(OM.downsample(C.rand_input('down', 40, 6), sd['weights']), G['down']['out'], **TOL)
+    sd = C.fill_state_dict(G['up']['keys'])
+    torch.testing.assert_close(OM.upsample(C.rand_input('up', 5, 6), sd['weights']), G['up']['out'], **TOL)
+    r = G['gdown']
+    sd = C.fill_state_dict(r['keys'])
+    torch.testing.assert_close(OM.graph_downsample(C.rand_input('gdown', N4, 8), doc, 4, sd, 2), r['out'], **TOL)
+    r = G['gup']
+    sd = C.fill_state_dict(r['keys'])
+    torch.testing.assert_close(OM.graph_upsample(C.rand_input('gup', N3, 8), doc, 3, sd, 3), r['out'], **TOL)
+    for name in ['vdown_same', 'vdown_diff']:
+        r = G[name]
+        sd = C.fill_state_dict(r['keys'])
+        y = OM.pool_rearrange(C.rand_input(name, N4, 8), doc, 4, sd['downsample.weights'])
+        if r['args'][1]:
+            y = OM.conv1x1_gn(y, doc, 3, OM._sub(sd, 'conv1x1'), gelu=True)
+        torch.testing.assert_close(y, r['out'], **TOL)
+    for name in ['vup_same', 'vup_diff']:
+        r = G[name]
+        sd = C.fill_state_dict(r['keys'])
+        y = OM.unpool_rearrange(C.rand_input(name, N3, 8), doc, 3, sd['upsample.weights'])
+        if r['args'][1]:
+            y = OM.conv1x1_gn(y, doc, 4, OM._sub(sd, 'conv1x1'), gelu=True)
+        torch.testing.assert_close(y, r['out'], **TOL)
+    for name in ['rbe_diff', 'rbe_same']:
+        r = G[name]
+        sd = C.fill_state_dict(r['keys'])
+        cin = r['args'][0]
+        y = OM.graph_resblock_embed(C.rand_input(name, N4, cin), C.rand_input(name + 'e', 2, 32),
+                                    doc, 4, sd, 3)
+        torch.testing.assert_close(y, r['out'], **TOL)
+    r = G['resblocks']
+    sd = C.fill_state_dict(r['keys'])
+    torch.testing.assert_close(OM.graph_resblocks(C.rand_input('resblocks', N4, 8), doc, 4, sd, 3),
+                               r['out'], **TOL)
+    r = G['c1x1gngelu']
+    sd = C.fill_state_dict(r['keys'])
+    torch.testing.assert_close(OM.conv1x1_gn(C.rand_input('c1x1gngelu', N4, 8), doc, 4, sd, gelu=True),
+                               r['out'], **TOL)
+
+
+def test_dense(golden):
+    G = golden('g_dense')
+    r = G['attn']
+    torch.testing.assert_close(OM.attention_block(r['x'], C.fill_state_dict(r['keys']), 4), r['out'], **TOL)
+    r = G['attn512']
+    torch.testing.assert_close(OM.attention_block(r['x'], C.fill_state_dict(r['keys']), 4), r['out'], **TOL)
+    r = G['resnet']
+    torch.testing.assert_close(OM.resnet_block(r['x'], r['emb'], C.fill_state_dict(r['keys'])), r['out'], **TOL)
+    r = G['lr']
+    sd = C.fill_state_dict(r['keys'])
+    torch.testing.assert_close(OU.lr_forward(sd, C.TINY_LR_CFG, r['x'], r['t'], r['x_self_cond']), r['out'], **TOL)
+    torch.testing.assert_close(OU.lr_forward(sd, C.TINY_LR_CFG, r['x'], r['t']), r['out_nosc'], **TOL)
+    oc, doc = small(G['split_small'])
+    m = G['lr_mid']
+    torch.testing.assert_close(OU.lr_forward_as_middle(sd, C.TINY_LR_CFG, m['h'], doc, m['t'], None),
+                               m['out'], **TOL)
+
+
+def split_union_sd(sd):
+    return {p: OM._sub(sd, p) for p in ('unet_lr', 'unet_hr', 'unet_feature')}
+
+
+def test_unet(golden):
+    G = golden('g_unet')
+    oc, doc = small(G['split_small'])
+    for name in ['uncond', 'cond']:
+        r = G[name]
+        parts = split_union_sd(C.fill_state_dict(r['keys']))
+        hr = dict(C.TINY_HR_CFG, num_classes=r['num_classes'])
+        lr = dict(C.TINY_LR_CFG, num_classes=r['num_classes'])
+        y = OU.hr_forward(parts['unet_hr'], hr, r['x'], doc, r['t'], r['label'], parts['unet_lr'], lr)
+        torch.testing.assert_close(y, r['out'], rtol=2e-4, atol=2e-5)
+    r = G['feature']
+    parts = split_union_sd(C.fill_state_dict(r['keys']))
+    oc_l = OS.split2octree_large(oc, r['split_large'], 5)
+    doc_l = OD.OracleDualOctree(oc_l)
+    doc_l.post_processing_for_docnn()
+    cfg = r['cfg']
+    feat = dict(input_depth=7, full_depth=3, model_channels=cfg['model_channels'][2],
+                channel_mult=cfg['channel_mult'][2], num_res_blocks=cfg['num_res_blocks'][2], num_classes=None)
+    mid = dict(kind='hr', input_depth=5, full_depth=3, model_channels=cfg['model_channels'][1],
+               channel_mult=cfg['channel_mult'][1], num_res_blocks=cfg['num_res_blocks'][1], num_classes=None)
+    y = OU.hr_forward(parts['unet_feature'], feat, r['x'], doc_l, r['t'], None, parts['unet_hr'], mid)
+    torch.testing.assert_close(y, r['out'], rtol=2e-4, atol=2e-5)
+
+
+def fake_net(shape):
+    A = torch.linspace(-0.5, 0.5, shape[1])
+
+    def net(x, noise_cond, x_self_cond):
+        a = A.view(1, -1, *([1] * (x.ndim - 2)))
+        tt = noise_cond.view(-1, *([1] * (x.ndim - 1))) if x.ndim > 2 else noise_cond[0]
+        y = torch.tanh(x * 0.7 + a) * 0.9 + 0.05 * torch.tanh(tt)
+        if x_self_cond is not None:
+            y = y + 0.1 * x_self_cond
+        return y
+    return net
+
+
+@pytest.mark.parametrize('name,unet_type,df_type', [('x0', 'lr', 'x0'), ('eps', 'hr', 'eps'), ('x0_graph', 'hr', 'x0')])
+def test_sample_loop(golden, name, unet_type, df_type):
+    r = golden('g_sample_loop')[name]
+    torch.manual_seed(r['seed'])
+    y = OS.sample_loop(fake_net(r['shape']), r['shape'], r['B'], r['steps'], unet_type, df_type,
+                       r.get('trunc', 0.0))
+    torch.testing.assert_close(y, r['out'], **TOL)

@@ -1,0 +1,218 @@
+/*
+ * ofx.h -- C ABI of libofx.so: the MI355X (gfx950) kernels behind OctFusion's
+ * denoising hot path.
+ *
+ * The reference (octree-nn/octfusion) has no FFI of its own: its boundary is
+ * Python nn.Module forward() calls that bottom out in torch ops.  This header
+ * is the C-ABI drop-in point *under* those modules: every entry point names the
+ * reference code it replaces (paths relative to the reference tree).  All
+ * pointers are DEVICE pointers unless the name ends in _host; `stream` is a
+ * hipStream_t passed as void*.  Every function returns 0 (OFX_OK) or a
+ * negative OFX_E* code; nothing throws, nothing allocates device memory,
+ * nothing synchronises (safe under hipGraph capture) unless stated.
+ *
+ * Layouts: features are row-major fp32 [rows, C] with an explicit leading
+ * dimension (floats); octree keys int64; children / indices int32.
+ */
+#ifndef OFX_H_
+#define OFX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFX_OK 0
+#define OFX_EINVAL (-1)   /* bad argument (shape / alignment / null)          */
+#define OFX_ELAUNCH (-2)  /* HIP launch error (hipGetLastError != success)    */
+#define OFX_ENODEV (-3)   /* no gfx950 device visible                         */
+
+#define OFX_ACT_NONE 0
+#define OFX_ACT_SILU 1
+#define OFX_ACT_GELU 2
+
+#define OFX_MAX_DEPTH 16
+
+int ofx_version(void);
+const char* ofx_status_string(int status);
+/* 0 when a HIP device is present and is gfx950; OFX_ENODEV otherwise. */
+int ofx_device_check(void);
+
+/* ------------------------------------------------------------------ scans */
+/* Exclusive prefix sum of n int32 values into out[0..n] (out[n] = total).
+ * ws: workspace of at least ofx_scan_ws_bytes(n) bytes.
+ * Replaces torch.cumsum uses in ocnn Octree.octree_split and
+ * dual_octree.py:265-271 (remap_node_idx). */
+size_t ofx_scan_ws_bytes(int64_t n);
+int ofx_scan_i32(const int32_t* in, int32_t* out, int64_t n, void* ws, void* stream);
+
+/* ---------------------------------------------------------------- octree
+ * Own octree container ops (ocnn.octree.Octree is third-party and absent;
+ * semantics per SURVEY.md 8c).  Call sites replaced:
+ * utils/util_dualoctree.py:225-273 (split2octree_small/large),
+ * ldm_diffusion_util.py:318-325 (create_full_octree),
+ * graph_vae.py:205-208,236-244 (octree_split / octree_grow). */
+
+/* keys[i] = (b << 48) | i_local, children[i] = i for a full layer of depth d. */
+int ofx_octree_full_layer(int depth, int batch_size, int64_t* keys, int32_t* children,
+                          void* stream);
+/* children[i] = label[i] ? rank : -1, where rank = excl_scan(label != 0).
+ * scan_out must hold n+1 int32 (scan_out[n] = number of non-empty nodes). */
+int ofx_octree_split(const int32_t* label, int64_t n, int32_t* children, int32_t* scan_out,
+                     void* ws, void* stream);
+/* keys_child[8*c + o] = ((key & m48) << 3 | o) | (key >> 48 << 48) for every
+ * parent with children[i] = c >= 0. */
+int ofx_octree_grow(const int64_t* keys_parent, const int32_t* children_parent, int64_t n_parent,
+                    int64_t* keys_child, int32_t* children_child, void* stream);
+/* split_small [B,8,S,S,S] (S = 2^full_depth) -> labels of the full layer
+ * (any channel > 0) -- util_dualoctree.py:233-238. */
+int ofx_split_small_label0(const float* split, int batch_size, int full_depth,
+                           int32_t* label, void* stream);
+/* labels of the 8 children of every non-empty full-layer node:
+ * label1[8*c + j] = split[b, j, x, y, z] > 0 -- util_dualoctree.py:242-246. */
+int ofx_split_small_label1(const float* split, int batch_size, int full_depth,
+                           const int32_t* children, int32_t* label1, void* stream);
+/* split_large [n, 8] -> label0[i] = any(split[i,:] > 0); label1[8*c + j] =
+ * split[i, j] > 0 for non-empty i -- util_dualoctree.py:258-269. */
+int ofx_split_large_label0(const float* split, int64_t n, int32_t* label0, void* stream);
+int ofx_split_large_label1(const float* split, int64_t n, const int32_t* children,
+                           int32_t* label1, void* stream);
+/* ocnn.nn.octree2voxel at the FULL layer followed by permute(0,4,1,2,3)
+ * (graph_unet_lr.py:176-177): data [B*8^d, C] -> vox [B, C, S, S, S]. */
+int ofx_octree2voxel_cf(const float* data, int64_t ld, int C, int batch_size, int depth,
+                        float* vox, void* stream);
+/* inverse gather (graph_unet_lr.py:179-181): vox [B, C, S,S,S] -> data [B*8^d, C]. */
+int ofx_voxel2octree_cf(const float* vox, int C, int batch_size, int depth, float* data,
+                        int64_t ld, void* stream);
+
+/* ------------------------------------------------------------ dual octree
+ * Neighbour graph of the dual octree (replaces DualOctree.__init__,
+ * dense_graph, sparse_graph, relative_dir, add_self_loops, remap_node_idx,
+ * add_node_type/keyd/mask, sort_edges, calc_batch_id:
+ * models/networks/dualoctree_networks/dual_octree.py:19-409).
+ *
+ * The tree is passed as the depth-concatenated arrays the reference itself
+ * builds (dual_octree.py:42-44): child_all / key_all of length ncum[depth+1],
+ * plus leafrank_all = per-depth exclusive scan of (child < 0).  nnum_host and
+ * nnum_nempty_host are HOST arrays of depth+1 entries.
+ *
+ * Graph nodes of depth d are numbered [leaves of full_depth..d-1 | all nodes
+ * of d] (dual_octree.py:265-271).  Edges come out grouped by (row, dir)
+ * segment, i.e. already in the reference's sort_edges order: seg_ptr has
+ * N_d*7+1 entries, col has E_d entries.  dir: 0:+z 1:-z 2:+y 3:-y 4:+x 5:-x
+ * 6:self. */
+typedef struct {
+  int depth, full_depth, batch_size;
+  const int32_t* child_all;
+  const int64_t* key_all;
+  const int32_t* leafrank_all;
+  const int64_t* nnum_host;
+  const int64_t* nnum_nempty_host;
+} ofx_tree_t;
+
+/* per-depth leaf ranks: leafrank_all[ncum[t] + j] = #leaves before j at depth t.
+ * ws: at least ofx_tree_leafrank_ws_bytes(max_d nnum[d]) bytes. */
+size_t ofx_tree_leafrank_ws_bytes(int64_t max_nnum);
+int ofx_tree_leafrank(const int32_t* child_all, const int64_t* nnum_host, int depth,
+                      int32_t* leafrank_all, void* ws, void* stream);
+/* node attributes of graph depth d: batch_id (key>>48), node_type (depth -
+ * full_depth), keyd (key | depth<<58), node_mask (leaf, or all-true at d).
+ * Any output may be NULL. */
+int ofx_graph_nodes(const ofx_tree_t* tree, int d, int32_t* batch_id, uint8_t* node_type,
+                    int64_t* keyd, uint8_t* node_mask, void* stream);
+/* pass 1: seg_cnt[r*7 + dir] = number of neighbours of graph node r through
+ * face dir (dir 6: 1 if the node has any neighbour). */
+int ofx_graph_count(const ofx_tree_t* tree, int d, int32_t* seg_cnt, void* stream);
+/* pass 2: col[seg_ptr[r*7+dir] ...] = neighbour ids (seg_ptr = excl. scan of seg_cnt). */
+int ofx_graph_fill(const ofx_tree_t* tree, int d, const int32_t* seg_ptr, int32_t* col,
+                   void* stream);
+/* CSR -> the reference's COO view: row[e], dir[e] (int64) for edge_idx / edge_dir. */
+int ofx_graph_expand(const int32_t* seg_ptr, int64_t n_nodes, const int32_t* col,
+                     int64_t* row_out, int64_t* col_out, int64_t* dir_out, void* stream);
+/* type_frac[r, dir*nt + t] = fraction of (r,dir)'s neighbours with node_type t; row
+ * pitch ld floats, columns >= 7*nt zero-filled up to ld.  This is the one-hot
+ * half of GraphConv's col_data (modules.py:199-210), constant per doctree. */
+int ofx_graph_type_frac(const int32_t* seg_ptr, const int32_t* col, const uint8_t* node_type,
+                        int64_t n_nodes, int nt, float* type_frac, int64_t ld, void* stream);
+
+/* ---------------------------------------------------------------- GEMM core
+ * Packed weight layout Wp[(k/4) * N + n][4] (k padded to Kp, multiple of 32,
+ * with zero rows).  ofx_pack_weights handles plain [K,N] (sk = N, sn = 1),
+ * transposed nn.Linear [N,K] (sk = 1, sn = K) and -- when cin > 0 -- the
+ * GraphConv row permutation: reference row dir*(cin+nt)+c (modules.py:174-176)
+ * -> packed k = dir*cin + c for features, 7*cin + dir*nt + t for node types. */
+int64_t ofx_packed_k(int64_t K);                       /* K rounded up to 32 */
+int64_t ofx_graphconv_packed_k(int cin, int nt);       /* 7*cin + pad32(7*nt)  */
+int ofx_pack_weights(const float* W, int64_t sk, int64_t sn, int64_t K, int64_t N,
+                     int cin, int nt, float* Wp, int64_t Kp, void* stream);
+
+/* out[orow(m), n] = sum_k A[arow(m), k] * W[k, n] + bias[n] + res[m, n]
+ * a_rows / out_rows: optional int32 row maps (NULL = identity); a negative
+ * out_rows entry skips the row.  Replaces torch mm / nn.Linear in
+ * Downsample/Upsample (modules.py:391-395, 440-443), Conv1x1 (:332-339), the
+ * time-embedding MLPs (graph_unet_hr.py:107-111). */
+int ofx_gemm_f32(const float* A, int64_t lda, const int32_t* a_rows, int64_t M, int64_t K,
+                 const float* Wp, int64_t Kp, int64_t N, const float* bias,
+                 const float* res, int64_t ldr, float* out, int64_t ldc,
+                 const int32_t* out_rows, void* stream);
+
+/* ---------------------------------------------------------------- GraphConv
+ * Fused dual-octree graph convolution (modules.py:194-220 + scatter.py:42-66):
+ *   out[r, :] = [ mean_{e in seg(r,dir)} x[col[e], :] for dir in 0..6 |
+ *                 type_frac[r, :] ] @ W  + bias + emb[batch_id[r], :] + res[r, :]
+ * The gather/segment-mean is done on the fly into LDS (col_data is never
+ * written to HBM); the contraction runs on fp32 MFMA.  emb/batch_id fuse the
+ * reference's per-batch-element time-embedding add (modules.py:754-758), res
+ * the residual / skip add (:763).  type_frac may be NULL (nt <= 1). */
+int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes,
+                      const int32_t* seg_ptr, const int32_t* col,
+                      const float* type_frac, int64_t ldt, int nt_pad,
+                      const float* Wp, int64_t Kp, int cout, const float* bias,
+                      const float* emb, int64_t lde, const int32_t* batch_id,
+                      const float* res, int64_t ldr, float* out, int64_t ldc, void* stream);
+
+/* Stand-alone segment-mean gather: col_data[r, dir, :] (the reference's
+ * `scatter_mean(x[col], row*7+dir)`, modules.py:208-210).  HBM-bound; used for
+ * the gather roofline measurement and as a building block. */
+int ofx_gather_mean(const float* x, int64_t ldx, int cin, int64_t n_nodes,
+                    const int32_t* seg_ptr, const int32_t* col, float* col_data,
+                    void* stream);
+
+/* ---------------------------------------------------------------- GroupNorm
+ * DualOctreeGroupNorm (modules.py:291-326): statistics per (batch element,
+ * group) over all nodes of that element.
+ *  stats:    sums[b, c, 0..1] += (sum x, sum x^2) in fp64 (zeroed inside).
+ *  finalize: mean/rstd [B, C] fp32 with the reference's inv_count =
+ *            1/(count*cpg + eps) and centred variance.
+ *  apply:    out = act((x - mean[b]) * rstd[b] * w + bias). */
+int ofx_gn_stats(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,
+                 int batch_size, double* sums, void* stream);
+int ofx_gn_finalize(const double* sums, const float* count, int batch_size, int C, int groups,
+                    float eps, float* mean, float* rstd, void* stream);
+int ofx_gn_apply(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,
+                 const float* mean, const float* rstd, const float* w, const float* bias,
+                 int act, float* out, int64_t ldo, void* stream);
+
+/* ---------------------------------------------------------------- glue ops */
+/* dst[dmap(i), 0:C] = src[smap(i), 0:C] for i < n (maps optional; negative skips). */
+int ofx_rows_copy(const float* src, int64_t lds, const int32_t* smap, float* dst, int64_t ldd,
+                  const int32_t* dmap, int64_t n, int C, void* stream);
+/* y = act(x) elementwise over n floats. */
+int ofx_act(const float* x, float* y, int64_t n, int act, void* stream);
+/* sinusoidal embedding of t[B] (ldm_diffusion_util.py:171-191): out [B, dim]. */
+int ofx_timestep_embedding(const float* t, int batch_size, int dim, float max_period,
+                           float* out, void* stream);
+/* DDIM eps-branch update (octfusion_model_union.py:345-350), coef on device:
+ * coef = {alpha, sigma, alpha_next, sigma_next}; x updated in place. */
+int ofx_ddim_eps_update(float* x, const float* eps, const float* coef, int64_t n, void* stream);
+/* DDIM x0-branch update (:326-344): x = mean + sqrt(var) * noise with
+ * coef = {alpha, c, alpha_next, sqrt(sigma_next^2 * c) or 0 when truncated}. */
+int ofx_ddim_x0_update(float* x, const float* x0, const float* noise, const float* coef,
+                       int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFX_H_ */

@@ -1,0 +1,119 @@
+"""ctypes binding of libofx.so (the C ABI declared in include/ofx.h).
+
+There is NO fallback: if the library is missing or a call returns a non-zero
+status the product raises.  Tensors cross the boundary as raw device pointers
+(`tensor.data_ptr()`), sizes as int64, the stream as `hipStream_t`.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libofx.so')
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_f = ctypes.c_float
+c_sz = ctypes.c_size_t
+
+
+class OfxTree(ctypes.Structure):
+    _fields_ = [('depth', c_i), ('full_depth', c_i), ('batch_size', c_i),
+                ('child_all', c_p), ('key_all', c_p), ('leafrank_all', c_p),
+                ('nnum_host', c_p), ('nnum_nempty_host', c_p)]
+
+
+# name -> (restype, argtypes, returns_status)
+_SIGS = {
+    'ofx_version': (c_i, [], False),
+    'ofx_status_string': (ctypes.c_char_p, [c_i], False),
+    'ofx_device_check': (c_i, [], False),
+    'ofx_scan_ws_bytes': (c_sz, [c_l], False),
+    'ofx_scan_i32': (c_i, [c_p, c_p, c_l, c_p, c_p], True),
+    'ofx_octree_full_layer': (c_i, [c_i, c_i, c_p, c_p, c_p], True),
+    'ofx_octree_split': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p], True),
+    'ofx_octree_grow': (c_i, [c_p, c_p, c_l, c_p, c_p, c_p], True),
+    'ofx_split_small_label0': (c_i, [c_p, c_i, c_i, c_p, c_p], True),
+    'ofx_split_small_label1': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p], True),
+    'ofx_split_large_label0': (c_i, [c_p, c_l, c_p, c_p], True),
+    'ofx_split_large_label1': (c_i, [c_p, c_l, c_p, c_p, c_p], True),
+    'ofx_octree2voxel_cf': (c_i, [c_p, c_l, c_i, c_i, c_i, c_p, c_p], True),
+    'ofx_voxel2octree_cf': (c_i, [c_p, c_i, c_i, c_i, c_p, c_l, c_p], True),
+    'ofx_tree_leafrank_ws_bytes': (c_sz, [c_l], False),
+    'ofx_tree_leafrank': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p], True),
+    'ofx_graph_nodes': (c_i, [ctypes.POINTER(OfxTree), c_i, c_p, c_p, c_p, c_p, c_p], True),
+    'ofx_graph_count': (c_i, [ctypes.POINTER(OfxTree), c_i, c_p, c_p], True),
+    'ofx_graph_fill': (c_i, [ctypes.POINTER(OfxTree), c_i, c_p, c_p, c_p], True),
+    'ofx_graph_expand': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_p], True),
+    'ofx_graph_type_frac': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_l, c_p], True),
+    'ofx_packed_k': (c_l, [c_l], False),
+    'ofx_graphconv_packed_k': (c_l, [c_i, c_i], False),
+    'ofx_pack_weights': (c_i, [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_p, c_l, c_p], True),
+    'ofx_gemm_f32': (c_i, [c_p, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p], True),
+    'ofx_graphconv_fwd': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_l, c_i, c_p, c_l, c_i, c_p,
+                                c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p], True),
+    'ofx_gather_mean': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p], True),
+    'ofx_gn_stats': (c_i, [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_p], True),
+    'ofx_gn_finalize': (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p], True),
+    'ofx_gn_apply': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p], True),
+    'ofx_rows_copy': (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_p], True),
+    'ofx_act': (c_i, [c_p, c_p, c_l, c_i, c_p], True),
+    'ofx_timestep_embedding': (c_i, [c_p, c_i, c_i, c_f, c_p, c_p], True),
+    'ofx_ddim_eps_update': (c_i, [c_p, c_p, c_p, c_l, c_p], True),
+    'ofx_ddim_x0_update': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p], True),
+}
+
+EXPORTS = sorted(_SIGS)
+
+
+class OfxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libofx.so (once).  Raises OfxError if it is missing -- no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OfxError('libofx.so not built: run `python -m octfusion_amd.build` '
+                           '(the product has no CPU / eager fallback)')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args, _) in _SIGS.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point; raise OfxError on failure."""
+    rc = getattr(lib(), name)(*args)
+    if _SIGS[name][2] and rc != 0:
+        msg = lib().ofx_status_string(rc).decode()
+        raise OfxError('%s failed: %s (%d)' % (name, msg, rc))
+    return rc
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device():
+    if not torch.cuda.is_available():
+        raise OfxError('no HIP device: octfusion_amd has no CPU path')
+    rc = lib().ofx_device_check()
+    if rc != 0:
+        raise OfxError('ofx_device_check: %s' % lib().ofx_status_string(rc).decode())

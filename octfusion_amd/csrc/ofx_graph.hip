@@ -1,0 +1,337 @@
+// libofx: dual-octree neighbour graph build (integer work; pointer chasing through
+// the child arrays, all reads of keys / children coalesced per node block).
+//
+// Replaces models/networks/dualoctree_networks/dual_octree.py:19-409.  The
+// reference refines an edge list level by level (dense_graph -> sparse_graph x
+// (depth - full_depth) -> add_self_loops -> remap_node_idx -> argsort).  Here each
+// graph node finds its face neighbours directly: walk the neighbour cell down
+// from the dense full layer through `children`; a leaf on the way is a single
+// coarser neighbour, a subdivided same-size cell (only possible when the node
+// itself is a coarser leaf) is expanded into its face-touching descendants.
+// Emitting per (row, dir) yields the reference's sorted-by-row*7+dir order with no
+// sort, and CSR segments come for free.  Output is bit-identical to the reference
+// after canonical (row, dir, col) ordering (tests/test_graph_parity.py).
+#include "ofx_common.h"
+
+struct TreeDev {
+  int depth, full_depth, batch_size;
+  const int32_t* child;
+  const int64_t* key;
+  const int32_t* leafrank;
+  int64_t ncum[OFX_MAX_DEPTH + 2];
+  int64_t nnum[OFX_MAX_DEPTH + 1];
+  int64_t leaf_base[OFX_MAX_DEPTH + 2];  // leaf_base[t] = sum_{s=fd}^{t-1} lnum[s]
+};
+
+static int make_tree(const ofx_tree_t* t, TreeDev& T) {
+  if (!t || t->depth < 0 || t->depth > OFX_MAX_DEPTH || t->full_depth < 0 || t->full_depth > t->depth ||
+      t->batch_size < 1 || !t->child_all || !t->key_all || !t->nnum_host || !t->nnum_nempty_host)
+    return OFX_EINVAL;
+  T.depth = t->depth;
+  T.full_depth = t->full_depth;
+  T.batch_size = t->batch_size;
+  T.child = t->child_all;
+  T.key = t->key_all;
+  T.leafrank = t->leafrank_all;
+  int64_t c = 0, lb = 0;
+  for (int d = 0; d <= OFX_MAX_DEPTH; ++d) {
+    T.ncum[d] = c;
+    T.leaf_base[d] = lb;
+    if (d <= t->depth) {
+      T.nnum[d] = t->nnum_host[d];
+      c += t->nnum_host[d];
+      if (d >= t->full_depth) lb += t->nnum_host[d] - t->nnum_nempty_host[d];
+    } else {
+      T.nnum[d] = 0;
+    }
+  }
+  T.ncum[OFX_MAX_DEPTH + 1] = c;
+  T.leaf_base[OFX_MAX_DEPTH + 1] = lb;
+  return OFX_OK;
+}
+
+static inline int64_t graph_nodes(const TreeDev& T, int d) { return T.leaf_base[d] + T.nnum[d]; }
+
+// graph row r of depth-d graph -> (tree depth t, index j inside depth t)
+__device__ __forceinline__ void row2node(const TreeDev& T, int d, int64_t r, int& t, int64_t& g) {
+  // blocks: leaves of fd..d-1 then all of d.  Few levels: linear search.
+  t = d;
+  for (int s = T.full_depth; s < d; ++s) {
+    if (r < T.leaf_base[s + 1]) { t = s; break; }
+  }
+  if (t == d) {
+    g = T.ncum[d] + (r - T.leaf_base[d]);
+  } else {
+    // the (r - leaf_base[t])-th leaf of depth t: binary search on leafrank (non-decreasing)
+    const int64_t want = r - T.leaf_base[t];
+    const int32_t* lr = T.leafrank + T.ncum[t];
+    const int32_t* ch = T.child + T.ncum[t];
+    int64_t lo = 0, hi = T.nnum[t] - 1;   // find largest j with leafrank[j] <= want, and child[j] < 0
+    while (lo < hi) {
+      int64_t mid = (lo + hi + 1) >> 1;
+      if (lr[mid] <= want) lo = mid; else hi = mid - 1;
+    }
+    // lo is the last j with leafrank <= want; that j is the leaf itself (rank increments after a leaf)
+    (void)ch;
+    g = T.ncum[t] + lo;
+  }
+}
+
+// compact id of tree node (t, j) in the depth-d graph
+__device__ __forceinline__ int32_t node2row(const TreeDev& T, int d, int t, int64_t j) {
+  if (t == d) return (int32_t)(T.leaf_base[d] + j);
+  return (int32_t)(T.leaf_base[t] + T.leafrank[T.ncum[t] + j]);
+}
+
+// face tables (dual_octree.py:85-97 semantics): dir 0:+z 1:-z 2:+y 3:-y 4:+x 5:-x
+__device__ __forceinline__ void dir_delta(int dir, int& dx, int& dy, int& dz) {
+  dx = dir == 4 ? 1 : (dir == 5 ? -1 : 0);
+  dy = dir == 2 ? 1 : (dir == 3 ? -1 : 0);
+  dz = dir == 0 ? 1 : (dir == 1 ? -1 : 0);
+}
+// the k-th (0..3) child octant lying on the face of a cell that looks in direction `dir`
+__device__ __forceinline__ int face_octant(int dir, int k) {
+  // axis bit: z=1, y=2, x=4; positive dirs want the bit set.
+  const int axis = dir >> 1;                  // 0:z 1:y 2:x
+  const int bit = 1 << axis;
+  const int set = (dir & 1) ? 0 : bit;
+  // spread k's two bits over the two other axes
+  int o;
+  if (axis == 0) o = (k << 1);                               // bits y,x <- k
+  else if (axis == 1) o = (k & 1) | ((k & 2) << 1);          // bits z,x
+  else o = k;                                                // bits z,y
+  return o | set;
+}
+
+// Enumerate neighbours of tree node (t, g) through face `dir` in the depth-d graph.
+// EMIT(row_id) is called for every neighbour.
+template <typename Emit>
+__device__ __forceinline__ void for_each_neighbour(const TreeDev& T, int d, int t, int64_t g, int dir, Emit emit) {
+  int x, y, z, b;
+  ofx_key2xyz(T.key[g], x, y, z, b);
+  int dx, dy, dz;
+  dir_delta(dir, dx, dy, dz);
+  const int nx = x + dx, ny = y + dy, nz = z + dz;
+  const int bnd = 1 << t;
+  if (nx < 0 || ny < 0 || nz < 0 || nx >= bnd || ny >= bnd || nz >= bnd) return;
+  const int fd = T.full_depth;
+  // start at the dense full layer
+  int sh = t - fd;
+  int64_t idx = ((int64_t)b << (3 * fd)) + (int64_t)ofx_xyz2morton(nx >> sh, ny >> sh, nz >> sh);
+  for (int s = fd; s < t; ++s) {
+    const int32_t c = T.child[T.ncum[s] + idx];
+    if (c < 0) { emit(node2row(T, d, s, idx)); return; }       // coarser leaf
+    sh = t - s - 1;
+    const int o = (((nx >> sh) & 1) << 2) | (((ny >> sh) & 1) << 1) | ((nz >> sh) & 1);
+    idx = (int64_t)c * 8 + o;
+  }
+  if (t == d) { emit(node2row(T, d, d, idx)); return; }
+  // same-size cell at depth t < d: leaf -> one neighbour, else expand the touching face
+  const int back = dir ^ 1;                                    // face of the neighbour that touches us
+  int32_t c0 = T.child[T.ncum[t] + idx];
+  if (c0 < 0) { emit(node2row(T, d, t, idx)); return; }
+  // DFS over face descendants; depth difference <= OFX_MAX_DEPTH
+  int64_t stack_idx[OFX_MAX_DEPTH];
+  int stack_k[OFX_MAX_DEPTH];
+  int sp = 0;
+  int cur_t = t + 1;                 // depth of the children we are iterating
+  stack_idx[0] = (int64_t)c0 * 8;    // base index of the children block at depth cur_t
+  stack_k[0] = 0;
+  while (sp >= 0) {
+    if (stack_k[sp] == 4) { --sp; --cur_t; continue; }
+    const int k = stack_k[sp]++;
+    const int64_t ci = stack_idx[sp] + face_octant(back, k);
+    if (cur_t == d) { emit(node2row(T, d, d, ci)); continue; }
+    const int32_t cc = T.child[T.ncum[cur_t] + ci];
+    if (cc < 0) { emit(node2row(T, d, cur_t, ci)); continue; }
+    ++sp; ++cur_t;
+    stack_idx[sp] = (int64_t)cc * 8;
+    stack_k[sp] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256) graph_count_kernel(TreeDev T, int d, int64_t N, int32_t* __restrict__ seg_cnt) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+    int t; int64_t g;
+    row2node(T, d, r, t, g);
+    int total = 0;
+    for (int dir = 0; dir < 6; ++dir) {
+      int cnt = 0;
+      for_each_neighbour(T, d, t, g, dir, [&](int32_t) { ++cnt; });
+      seg_cnt[r * 7 + dir] = cnt;
+      total += cnt;
+    }
+    seg_cnt[r * 7 + 6] = total > 0 ? 1 : 0;   // add_self_loops: every row that has an edge
+  }
+}
+
+__global__ void __launch_bounds__(256) graph_fill_kernel(TreeDev T, int d, int64_t N,
+                                                         const int32_t* __restrict__ seg_ptr,
+                                                         int32_t* __restrict__ col) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+    int t; int64_t g;
+    row2node(T, d, r, t, g);
+    for (int dir = 0; dir < 6; ++dir) {
+      int32_t p = seg_ptr[r * 7 + dir];
+      for_each_neighbour(T, d, t, g, dir, [&](int32_t id) { col[p++] = id; });
+    }
+    if (seg_ptr[r * 7 + 7] > seg_ptr[r * 7 + 6]) col[seg_ptr[r * 7 + 6]] = (int32_t)r;
+  }
+}
+
+__global__ void __launch_bounds__(256) graph_nodes_kernel(TreeDev T, int d, int64_t N, int32_t* __restrict__ batch_id,
+                                                          uint8_t* __restrict__ node_type, int64_t* __restrict__ keyd,
+                                                          uint8_t* __restrict__ node_mask) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+    int t; int64_t g;
+    row2node(T, d, r, t, g);
+    const int64_t key = T.key[g];
+    if (batch_id) batch_id[r] = (int32_t)((uint64_t)key >> 48);
+    if (node_type) node_type[r] = (uint8_t)(t - T.full_depth);
+    if (keyd) keyd[r] = key | ((int64_t)t << 58);
+    if (node_mask) node_mask[r] = 1;
+  }
+}
+
+// node_mask of the depth-d graph has length leaf_base[d] + nnum[d] but marks which of
+// [all nodes of fd..d-1 | nodes of d] ... see dual_octree.py:391-398: it is the
+// concatenation of the leaf masks of depths fd..d-1 (over ALL nodes of those depths) and
+// ones(nnum[d]).  Separate kernel because its length differs from N_d.
+__global__ void node_mask_kernel(TreeDev T, int d, int64_t total, uint8_t* __restrict__ mask) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t g = T.ncum[T.full_depth] + i;    // tree node, depths fd..d concatenated
+    mask[i] = (g >= T.ncum[d]) ? 1 : (T.child[g] < 0);
+  }
+}
+
+__global__ void leaf_flag_kernel(const int32_t* __restrict__ child, int64_t n, int32_t* __restrict__ flag) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    flag[i] = child[i] < 0;
+}
+
+extern "C" size_t ofx_tree_leafrank_ws_bytes(int64_t max_nnum) {
+  const int64_t mx = max_nnum > 1 ? max_nnum : 1;
+  return ((ofx_scan_ws_bytes(mx) + 255) & ~(size_t)255) + (((size_t)mx * 4 + 255) & ~(size_t)255) +
+         (size_t)(mx + 1) * 4 + 256;
+}
+
+extern "C" int ofx_tree_leafrank(const int32_t* child_all, const int64_t* nnum_host, int depth,
+                                 int32_t* leafrank_all, void* ws, void* stream) {
+  if (!child_all || !nnum_host || !leafrank_all || !ws || depth < 0 || depth > OFX_MAX_DEPTH) return OFX_EINVAL;
+  // ws layout: [scan workspace | flag buffer (max nnum) | scan out (max nnum + 1)]
+  int64_t mx = 1;
+  for (int d = 0; d <= depth; ++d) mx = nnum_host[d] > mx ? nnum_host[d] : mx;
+  char* base = (char*)ws;
+  size_t off = (ofx_scan_ws_bytes(mx) + 255) & ~(size_t)255;
+  int32_t* flag = (int32_t*)(base + off);
+  off += ((size_t)mx * 4 + 255) & ~(size_t)255;
+  int32_t* sout = (int32_t*)(base + off);
+  hipStream_t st = ofx_stream(stream);
+  int64_t c = 0;
+  for (int d = 0; d <= depth; ++d) {
+    const int64_t n = nnum_host[d];
+    if (n > 0) {
+      leaf_flag_kernel<<<ofx_grid(n, 256), 256, 0, st>>>(child_all + c, n, flag);
+      int rc = ofx_scan_i32(flag, sout, n, ws, stream);
+      if (rc) return rc;
+      if (hipMemcpyAsync(leafrank_all + c, sout, (size_t)n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return OFX_ELAUNCH;
+    }
+    c += n;
+  }
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+extern "C" int ofx_graph_nodes(const ofx_tree_t* tree, int d, int32_t* batch_id, uint8_t* node_type,
+                               int64_t* keyd, uint8_t* node_mask, void* stream) {
+  TreeDev T;
+  int rc = make_tree(tree, T);
+  if (rc) return rc;
+  if (d < T.full_depth || d > T.depth || !T.leafrank) return OFX_EINVAL;
+  const int64_t N = graph_nodes(T, d);
+  hipStream_t st = ofx_stream(stream);
+  if (batch_id || node_type || keyd)
+    graph_nodes_kernel<<<ofx_grid(N, 256), 256, 0, st>>>(T, d, N, batch_id, node_type, keyd, nullptr);
+  if (node_mask) {
+    const int64_t total = T.ncum[d] + T.nnum[d] - T.ncum[T.full_depth];
+    node_mask_kernel<<<ofx_grid(total, 256), 256, 0, st>>>(T, d, total, node_mask);
+  }
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+extern "C" int ofx_graph_count(const ofx_tree_t* tree, int d, int32_t* seg_cnt, void* stream) {
+  TreeDev T;
+  int rc = make_tree(tree, T);
+  if (rc) return rc;
+  if (d < T.full_depth || d > T.depth || !seg_cnt || !T.leafrank) return OFX_EINVAL;
+  const int64_t N = graph_nodes(T, d);
+  graph_count_kernel<<<ofx_grid(N, 256), 256, 0, ofx_stream(stream)>>>(T, d, N, seg_cnt);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+extern "C" int ofx_graph_fill(const ofx_tree_t* tree, int d, const int32_t* seg_ptr, int32_t* col, void* stream) {
+  TreeDev T;
+  int rc = make_tree(tree, T);
+  if (rc) return rc;
+  if (d < T.full_depth || d > T.depth || !seg_ptr || !col || !T.leafrank) return OFX_EINVAL;
+  const int64_t N = graph_nodes(T, d);
+  graph_fill_kernel<<<ofx_grid(N, 256), 256, 0, ofx_stream(stream)>>>(T, d, N, seg_ptr, col);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+__global__ void graph_expand_kernel(const int32_t* __restrict__ seg_ptr, int64_t nseg, const int32_t* __restrict__ col,
+                                    int64_t* __restrict__ row_out, int64_t* __restrict__ col_out,
+                                    int64_t* __restrict__ dir_out) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t a = seg_ptr[s], e = seg_ptr[s + 1];
+    const int64_t r = s / 7, dir = s - r * 7;
+    for (int32_t p = a; p < e; ++p) {
+      if (row_out) row_out[p] = r;
+      if (dir_out) dir_out[p] = dir;
+      if (col_out) col_out[p] = col[p];
+    }
+  }
+}
+
+extern "C" int ofx_graph_expand(const int32_t* seg_ptr, int64_t n_nodes, const int32_t* col, int64_t* row_out,
+                                int64_t* col_out, int64_t* dir_out, void* stream) {
+  if (!seg_ptr || n_nodes < 0 || (col_out && !col)) return OFX_EINVAL;
+  graph_expand_kernel<<<ofx_grid(n_nodes * 7, 256), 256, 0, ofx_stream(stream)>>>(seg_ptr, n_nodes * 7, col, row_out,
+                                                                                 col_out, dir_out);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+__global__ void type_frac_kernel(const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ col,
+                                 const uint8_t* __restrict__ node_type, int64_t N, int nt, float* __restrict__ tf,
+                                 int64_t ld) {
+  // one thread per (row, dir); writes nt floats.  Pad columns are zeroed by thread dir==6.
+  const int64_t nseg = N * 7;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t a = seg_ptr[s], e = seg_ptr[s + 1];
+    const int64_t r = s / 7;
+    const int dir = (int)(s - r * 7);
+    float* o = tf + r * ld + dir * nt;
+    const float inv = 1.f / (float)(e - a > 1 ? e - a : 1);
+    for (int t = 0; t < nt; ++t) {
+      int c = 0;
+      for (int32_t p = a; p < e; ++p) c += node_type[col[p]] == t;
+      o[t] = (float)c * inv;
+    }
+    if (dir == 6)
+      for (int64_t k = 7 * nt; k < ld; ++k) tf[r * ld + k] = 0.f;
+  }
+}
+
+extern "C" int ofx_graph_type_frac(const int32_t* seg_ptr, const int32_t* col, const uint8_t* node_type,
+                                   int64_t n_nodes, int nt, float* type_frac, int64_t ld, void* stream) {
+  if (!seg_ptr || !col || !node_type || !type_frac || nt < 1 || ld < 7 * nt || n_nodes < 0) return OFX_EINVAL;
+  type_frac_kernel<<<ofx_grid(n_nodes * 7, 256), 256, 0, ofx_stream(stream)>>>(seg_ptr, col, node_type, n_nodes, nt,
+                                                                              type_frac, ld);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}

@@ -1,0 +1,173 @@
+// libofx: DualOctreeGroupNorm (reference models/networks/modules.py:262-330).
+// HBM-bound: stats = one read of x, apply = one read + one write (the reference
+// makes 3 scatter_add passes + 2 index_selects, ~7 passes).
+//
+// Statistics are accumulated per (batch element, channel) as fp64 (sum, sum of
+// squares): fp32 per-thread partials over <= 64 rows, fp64 across threads / blocks
+// (LDS then global atomics).  finalize reproduces the reference's arithmetic:
+// inv_count = 1/(count*cpg + eps), mean = S*inv_count, centred variance
+// sum((x-mean)^2)*inv_count = (SS - 2*mean*S + n*mean^2)*inv_count evaluated in
+// fp64, rstd = 1/sqrt(var + eps).
+#include "ofx_common.h"
+
+constexpr int GN_ROWS_PER_BLOCK = 512;
+
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int C,
+                                                       const int32_t* __restrict__ bid, double* __restrict__ sums) {
+  __shared__ int sb[256];
+  __shared__ float sv[256][8];
+  const int CT = C >> 2;                 // float4 lanes per row (<= 256)
+  const int RP = 256 / CT;               // rows per pass
+  const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
+  const int64_t r_begin = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK;
+  const int64_t r_end = r_begin + GN_ROWS_PER_BLOCK < n ? r_begin + GN_ROWS_PER_BLOCK : n;
+  int cb = -1;
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  auto flush_direct = [&](int b, const float* ps, const float* pq) {
+    if (b < 0) return;
+    double* o = sums + ((int64_t)b * C + cl * 4) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(o + 2 * k, (double)ps[k]);
+      atomicAdd(o + 2 * k + 1, (double)pq[k]);
+    }
+  };
+  if (rl < RP) {
+    for (int64_t r = r_begin + rl; r < r_end; r += RP) {
+      const int b = bid[r];
+      if (b != cb) {
+        flush_direct(cb, s, q);
+        cb = b;
+        s[0] = s[1] = s[2] = s[3] = 0.f;
+        q[0] = q[1] = q[2] = q[3] = 0.f;
+      }
+      const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + cl * 4);
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+    }
+  }
+  sb[threadIdx.x] = (rl < RP) ? cb : -1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sv[threadIdx.x][k] = s[k]; sv[threadIdx.x][4 + k] = q[k]; }
+  __syncthreads();
+  if (rl == 0) {
+    double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+    for (int j = 0; j < RP; ++j) {
+      const int t = j * CT + cl;
+      const int b = sb[t];
+      if (b < 0) continue;
+      if (b == cb) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ds[k] += (double)sv[t][k]; dq[k] += (double)sv[t][4 + k]; }
+      } else {
+        flush_direct(b, &sv[t][0], &sv[t][4]);
+      }
+    }
+    if (cb >= 0) {
+      double* o = sums + ((int64_t)cb * C + cl * 4) * 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { atomicAdd(o + 2 * k, ds[k]); atomicAdd(o + 2 * k + 1, dq[k]); }
+    }
+  }
+}
+
+extern "C" int ofx_gn_stats(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id, int batch_size,
+                            double* sums, void* stream) {
+  if (!x || !batch_id || !sums || n < 0 || C < 4 || (C & 3) || C > 1024 || ldx < C || (ldx & 3) ||
+      ((uintptr_t)x & 15) || batch_size < 1)
+    return OFX_EINVAL;
+  hipStream_t st = ofx_stream(stream);
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)batch_size * C, st) != hipSuccess) return OFX_ELAUNCH;
+  if (n > 0) gn_stats_kernel<<<(int)ofx_cdiv(n, GN_ROWS_PER_BLOCK), 256, 0, st>>>(x, ldx, n, C, batch_id, sums);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ count, int B, int C, int G,
+                                   float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+  const int cpg = C / G;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < B * G; t += gridDim.x * blockDim.x) {
+    const int b = t / G, g = t - b * G;
+    double S = 0, SS = 0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      S += sums[((int64_t)b * C + c) * 2];
+      SS += sums[((int64_t)b * C + c) * 2 + 1];
+    }
+    const float cnt = count[b] * (float)cpg;            // modules.py:301-302 (fp32)
+    const float inv = 1.0f / (cnt + eps);
+    const double m = S * (double)inv;
+    const double ssd = SS - 2.0 * m * S + (double)cnt * m * m;
+    const double var = (ssd > 0 ? ssd : 0) * (double)inv;
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      mean[(int64_t)b * C + c] = (float)m;
+      rstd[(int64_t)b * C + c] = rs;
+    }
+  }
+}
+
+extern "C" int ofx_gn_finalize(const double* sums, const float* count, int batch_size, int C, int groups, float eps,
+                               float* mean, float* rstd, void* stream) {
+  if (!sums || !count || !mean || !rstd || batch_size < 1 || C < 1 || groups < 1 || C % groups) return OFX_EINVAL;
+  gn_finalize_kernel<<<ofx_grid((int64_t)batch_size * groups, 64), 64, 0, ofx_stream(stream)>>>(
+      sums, count, batch_size, C, groups, eps, mean, rstd);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+__device__ __forceinline__ float ofx_apply_act(float v, int act) {
+  if (act == OFX_ACT_SILU) return v / (1.f + __expf(-v));
+  if (act == OFX_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  return v;
+}
+
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int C,
+                                                       const int32_t* __restrict__ bid, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, int act, float* __restrict__ out,
+                                                       int64_t ldo) {
+  const int CT = C >> 2;
+  const int64_t total = n * CT;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / CT;
+    const int c = (int)(t - r * CT) * 4;
+    const int b = bid[r];
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    const float4 m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c);
+    const float4 rs = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c);
+    const float4 ww = *reinterpret_cast<const float4*>(w + c);
+    const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+    float4 o;
+    o.x = ofx_apply_act((v.x - m.x) * rs.x * ww.x + bb.x, act);
+    o.y = ofx_apply_act((v.y - m.y) * rs.y * ww.y + bb.y, act);
+    o.z = ofx_apply_act((v.z - m.z) * rs.z * ww.z + bb.z, act);
+    o.w = ofx_apply_act((v.w - m.w) * rs.w * ww.w + bb.w, act);
+    *reinterpret_cast<float4*>(out + r * ldo + c) = o;
+  }
+}
+
+extern "C" int ofx_gn_apply(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id, const float* mean,
+                            const float* rstd, const float* w, const float* bias, int act, float* out, int64_t ldo,
+                            void* stream) {
+  if (!x || !batch_id || !mean || !rstd || !w || !bias || !out || n < 0 || C < 4 || (C & 3) || ldx < C || ldo < C ||
+      (ldx & 3) || (ldo & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)w & 15) ||
+      ((uintptr_t)bias & 15) || ((uintptr_t)mean & 15) || ((uintptr_t)rstd & 15) || act < 0 || act > 2)
+    return OFX_EINVAL;
+  if (n > 0)
+    gn_apply_kernel<<<ofx_grid(n * (C / 4), 256), 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, batch_id, mean, rstd, w,
+                                                                                bias, act, out, ldo);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+// elementwise activation (shared with ofx_misc entry point)
+__global__ void act_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = ofx_apply_act(x[i], act);
+}
+extern "C" int ofx_act(const float* x, float* y, int64_t n, int act, void* stream) {
+  if (n < 0 || (n > 0 && (!x || !y)) || act < 0 || act > 2) return OFX_EINVAL;
+  if (n > 0) act_kernel<<<ofx_grid(n, 256), 256, 0, ofx_stream(stream)>>>(x, y, n, act);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}

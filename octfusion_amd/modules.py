@@ -1,0 +1,352 @@
+"""nn.Module mirrors of the reference's dual-octree building blocks.
+
+Constructor arguments, ``forward`` signatures, parameter names and shapes follow
+reference models/networks/modules.py (cited per class) so checkpoints load with
+``strict=True`` and callers (graph_unet_hr / graph_vae) need no change.  The
+bodies do not: every forward is a short sequence of libofx launches
+(octfusion_amd.ops) -- fused gather+contraction GraphConv, two-kernel GroupNorm
+with fused SiLU, row-map pool / unpool -- with no boolean-mask indexing (hence no
+host sync inside a denoising step) and no materialised ``col_data``.
+
+Inference only (the sampling path runs under no_grad): these
+modules do not build an autograd graph.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _gn_groups(channels, group=32):
+    # reference modules.py:271-280
+    if channels <= 32:
+        group = channels // 4
+    elif channels % group != 0:
+        group = 30
+    assert channels % group == 0
+    return group
+
+
+class GraphConv(nn.Module):
+    """reference modules.py:163-220."""
+
+    def __init__(self, in_channels, out_channels, n_edge_type=7, avg_degree=7, n_node_type=0,
+                 use_bias=False):
+        super().__init__()
+        assert n_edge_type == 7, 'the dual octree graph has 7 edge types'
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.use_bias = use_bias
+        self.n_edge_type = n_edge_type
+        self.avg_degree = avg_degree
+        self.n_node_type = n_node_type
+        node_channel = n_node_type if n_node_type > 1 else 0
+        self.weights = nn.Parameter(torch.empty(n_edge_type * (in_channels + node_channel), out_channels))
+        if use_bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        self.reset_parameters()
+        self._pw = ops.PackedWeight()
+
+    def reset_parameters(self):
+        fan_in = self.avg_degree * self.in_channels
+        fan_out = self.avg_degree * self.out_channels
+        a = math.sqrt(3.0) * math.sqrt(2.0 / float(fan_in + fan_out))
+        nn.init.uniform_(self.weights, -a, a)
+        if self.use_bias:
+            nn.init.zeros_(self.bias)
+
+    @torch.no_grad()
+    def forward(self, x, doctree, d, emb=None, res=None, out=None):
+        """``emb`` [B, Cout] (added per batch element) and ``res`` [N, Cout] are optional
+        fused epilogue terms (the reference adds them with separate ops)."""
+        nt = self.n_node_type if self.n_node_type > 1 else 0
+        pw = self._pw.get(self.weights, 'graphconv', self.in_channels, nt)
+        seg_ptr, col, N, E = doctree.csr(d)
+        assert x.shape[0] == N, 'x has %d rows, graph depth %d has %d nodes' % (x.shape[0], d, N)
+        tf = doctree.type_frac(d, nt) if nt else None
+        return ops.graphconv(x, seg_ptr, col, pw, self.in_channels, tf,
+                             self.bias if self.use_bias else None, emb,
+                             doctree.batch_id32(d) if emb is not None else None, res, out)
+
+    def extra_repr(self):
+        return 'channel_in={}, channel_out={}, n_edge_type={}, avg_degree={}, n_node_type={}'.format(
+            self.in_channels, self.out_channels, self.n_edge_type, self.avg_degree, self.n_node_type)
+
+
+class DualOctreeGroupNorm(nn.Module):
+    """reference modules.py:262-330."""
+
+    def __init__(self, in_channels, group=32, nempty=False):
+        super().__init__()
+        self.eps = 1e-5
+        self.nempty = nempty
+        self.in_channels = in_channels
+        self.group = _gn_groups(in_channels, group)
+        self.channels_per_group = in_channels // self.group
+        self.weights = nn.Parameter(torch.ones(1, in_channels))
+        self.bias = nn.Parameter(torch.zeros(1, in_channels))
+
+    @torch.no_grad()
+    def forward(self, data, doctree, depth, act=None, out=None):
+        assert doctree.batch_id32(depth).shape[0] == data.shape[0]
+        return ops.group_norm(data, doctree.batch_id32(depth), doctree.count(depth), doctree.batch_size,
+                              self.weights, self.bias, self.group, self.eps, act, out)
+
+    def extra_repr(self):
+        return 'in_channels={}, group={}, nempty={}'.format(self.in_channels, self.group, self.nempty)
+
+
+class _Linear(nn.Module):
+    """nn.Linear-compatible parameters (``weight`` [out, in], ``bias``) on the MFMA GEMM."""
+
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = cin, cout
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(cin)
+            nn.init.uniform_(self.bias, -bound, bound)
+        self._pw = ops.PackedWeight()
+
+    @torch.no_grad()
+    def forward(self, x, res=None, out=None):
+        return ops.gemm(x, self._pw.get(self.weight, 'nk'), self.bias, res, out)
+
+
+class Conv1x1(nn.Module):
+    """reference modules.py:332-339 (``linear.weight`` / ``linear.bias``)."""
+
+    def __init__(self, channel_in, channel_out, use_bias=False):
+        super().__init__()
+        self.linear = _Linear(channel_in, channel_out, use_bias)
+
+    def forward(self, x, res=None):
+        return self.linear(x, res)
+
+
+class Conv1x1Gn(nn.Module):
+    """reference modules.py:341-351."""
+
+    def __init__(self, channel_in, channel_out):
+        super().__init__()
+        self.conv = Conv1x1(channel_in, channel_out, use_bias=False)
+        self.gn = DualOctreeGroupNorm(channel_out)
+
+    def forward(self, x, doctree, depth):
+        return self.gn(self.conv(x), doctree, depth)
+
+
+class Conv1x1GnGelu(nn.Module):
+    """reference modules.py:353-365."""
+
+    def __init__(self, channel_in, channel_out):
+        super().__init__()
+        self.conv = Conv1x1(channel_in, channel_out, use_bias=False)
+        self.gn = DualOctreeGroupNorm(channel_out)
+        self.gelu = nn.GELU()
+
+    def forward(self, x, doctree, depth):
+        return self.gn(self.conv(x), doctree, depth, act='gelu')
+
+
+class Conv1x1GnGeluSequential(Conv1x1GnGelu):
+    """reference modules.py:367-380 (takes a (x, doctree, depth) tuple)."""
+
+    def forward(self, data):
+        x, doctree, depth = data
+        return super().forward(x, doctree, depth)
+
+
+class Downsample(nn.Module):
+    """reference modules.py:382-398: [8n, C] -> [n, C] with ``weights`` [C, C, 8]."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.channels = channels
+        self.weights = nn.Parameter(torch.empty(channels, channels, 8))
+        nn.init.xavier_uniform_(self.weights)
+        self._pw = ops.PackedWeight()
+
+    def packed(self):
+        # x.view(-1, 8C) @ W.flatten(1).t()  ==  nn.Linear layout [N=C, K=8C]
+        return self._pw.get(self.weights.view(self.channels, self.channels * 8), 'nk')
+
+    @torch.no_grad()
+    def forward(self, x, out=None, out_rows=None):
+        return ops.gemm(x.reshape(-1, self.channels * 8), self.packed(), out=out, out_rows=out_rows)
+
+    def extra_repr(self):
+        return 'channels={}'.format(self.channels)
+
+
+class Upsample(nn.Module):
+    """reference modules.py:430-446: [n, C] -> [8n, C]."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.channels = channels
+        self.weights = nn.Parameter(torch.empty(channels, channels, 8))
+        nn.init.xavier_uniform_(self.weights)
+        self._pw = ops.PackedWeight()
+
+    def packed(self):
+        # x @ W.flatten(1): plain [K=C, N=8C]
+        return self._pw.get(self.weights.view(self.channels, self.channels * 8), 'kn')
+
+    @torch.no_grad()
+    def forward(self, x, a_rows=None, out=None):
+        y = ops.gemm(x, self.packed(), out=out, a_rows=a_rows)
+        return y.view(-1, self.channels) if out is None else out
+
+    def extra_repr(self):
+        return 'channels={}'.format(self.channels)
+
+
+def pool_nodes(x, doctree, d, downsample):
+    """Rows of graph depth d -> rows of depth d-1 (reference modules.py:409-423, without masks)."""
+    copy_src, gemm_rows, n_out = doctree.pool_maps(d)
+    C = x.shape[1]
+    numd = int(doctree.nnum[d])
+    out = torch.empty(n_out, C, dtype=torch.float32, device=x.device)
+    ops.rows_copy(x, out, n_out, smap=copy_src)
+    downsample(x[x.shape[0] - numd:], out=out, out_rows=gemm_rows)
+    return out
+
+
+def unpool_nodes(x, doctree, d, upsample):
+    """Rows of graph depth d -> rows of depth d+1 (reference modules.py:458-467)."""
+    copy_src, a_rows, n_copy = doctree.unpool_maps(d)
+    C = x.shape[1]
+    n_ne = a_rows.numel()
+    out = torch.empty(n_copy + 8 * n_ne, C, dtype=torch.float32, device=x.device)
+    ops.rows_copy(x, out, n_copy, smap=copy_src)
+    if n_ne:
+        upsample(x, a_rows=a_rows, out=out[n_copy:].view(n_ne, 8 * C))
+    return out
+
+
+class GraphDownsample(nn.Module):
+    """reference modules.py:400-428 (U-Net flavour; ``d`` = depth of the INPUT)."""
+
+    def __init__(self, channels_in, channels_out, n_edge_type, avg_degree, n_node_type):
+        super().__init__()
+        self.channels_in = channels_in
+        self.channels_out = channels_out
+        self.downsample = Downsample(channels_in)
+        self.conv = GraphConv(channels_in, channels_out, n_edge_type, avg_degree, n_node_type)
+
+    def forward(self, x, doctree, d):
+        return self.conv(pool_nodes(x, doctree, d, self.downsample), doctree, d - 1)
+
+
+class GraphUpsample(nn.Module):
+    """reference modules.py:449-472 (U-Net flavour; ``d`` = depth of the INPUT)."""
+
+    def __init__(self, channels_in, channels_out, n_edge_type, avg_degree, n_node_type):
+        super().__init__()
+        self.channels_in = channels_in
+        self.channels_out = channels_out
+        self.upsample = Upsample(channels_in)
+        self.conv = GraphConv(channels_in, channels_out, n_edge_type, avg_degree, n_node_type)
+
+    def forward(self, x, doctree, d):
+        return self.conv(unpool_nodes(x, doctree, d, self.upsample), doctree, d + 1)
+
+
+def graphnormalization(channels):
+    return DualOctreeGroupNorm(channels, min(32, channels))
+
+
+class TimestepBlock(nn.Module):
+    pass
+
+
+class GraphResBlockEmbed(TimestepBlock):
+    """reference modules.py:661-763.  use_scale_shift_norm must stay False (the reference
+    branch reads a non-existent attribute, :747-751)."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels, n_edge_type, avg_degree,
+                 n_node_type, use_conv=False, use_scale_shift_norm=False, dims=2,
+                 use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        if use_scale_shift_norm or use_conv:
+            raise NotImplementedError('use_scale_shift_norm / use_conv are dead in the reference')
+        self.channels = channels
+        self.emb_channels = emb_channels
+        self.out_channels = channels if out_channels is None else out_channels
+        self.use_checkpoint = use_checkpoint
+        self.block1_norm = graphnormalization(self.channels)
+        self.silu = nn.SiLU()
+        self.conv1 = GraphConv(self.channels, self.out_channels, n_edge_type, avg_degree, n_node_type)
+        self.emb_layers = nn.Sequential(nn.SiLU(), _Linear(emb_channels, self.out_channels))
+        self.block2_norm = graphnormalization(self.out_channels)
+        self.dropout = nn.Dropout(p=dropout)
+        self.conv2 = GraphConv(self.out_channels, self.out_channels, n_edge_type, avg_degree, n_node_type)
+        for p in self.conv2.parameters():        # zero_module (:719)
+            p.detach().zero_()
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = Conv1x1(self.channels, self.out_channels)
+
+    @torch.no_grad()
+    def forward(self, x, emb, doctree, depth, emb_act=None):
+        """``emb_act``: optional precomputed SiLU(emb) shared by all blocks of a step."""
+        h = self.block1_norm(x, doctree, depth, act='silu')
+        if emb_act is None:
+            emb_act = ops.act(emb, 'silu')
+        emb_out = self.emb_layers[1](emb_act)                       # [B, Cout]
+        assert doctree.batch_size == emb_out.shape[0]
+        h = self.conv1(h, doctree, depth, emb=emb_out)              # + emb_out[batch_id] fused
+        h = self.block2_norm(h, doctree, depth, act='silu', out=h)
+        skip = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x)
+        return self.conv2(h, doctree, depth, res=skip)              # skip + h fused
+
+
+class GraphResBlock(nn.Module):
+    """reference modules.py:593-641 (VAE flavour)."""
+
+    def __init__(self, channel_in, channel_out, dropout, n_edge_type=7, avg_degree=7, n_node_type=0,
+                 use_checkpoint=False):
+        super().__init__()
+        self.channel_in = channel_in
+        self.channel_out = channel_out
+        self.use_checkpoint = use_checkpoint
+        self.norm1 = DualOctreeGroupNorm(channel_in)
+        self.conv1 = GraphConv(channel_in, channel_out, n_edge_type, avg_degree, n_node_type)
+        self.norm2 = DualOctreeGroupNorm(channel_out)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = GraphConv(channel_out, channel_out, n_edge_type, avg_degree, n_node_type)
+        if channel_in != channel_out:
+            self.conv1x1c = Conv1x1Gn(channel_in, channel_out)
+
+    @torch.no_grad()
+    def forward(self, x, doctree, depth):
+        h = self.norm1(x, doctree, depth, act='silu')
+        h = self.conv1(h, doctree, depth)
+        h = self.norm2(h, doctree, depth, act='silu', out=h)
+        if self.channel_in != self.channel_out:
+            x = self.conv1x1c(x, doctree, depth)
+        return self.conv2(h, doctree, depth, res=x)
+
+
+class GraphResBlocks(nn.Module):
+    """reference modules.py:643-659."""
+
+    def __init__(self, channel_in, channel_out, dropout, resblk_num, n_edge_type=7, avg_degree=7,
+                 n_node_type=0, use_checkpoint=False):
+        super().__init__()
+        self.resblk_num = resblk_num
+        channels = [channel_in] + [channel_out] * resblk_num
+        self.resblks = nn.ModuleList([
+            GraphResBlock(channels[i], channels[i + 1], dropout, n_edge_type, avg_degree, n_node_type,
+                          use_checkpoint) for i in range(resblk_num)])
+
+    def forward(self, data, doctree, depth):
+        for blk in self.resblks:
+            data = blk(data, doctree, depth)
+        return data

@@ -1,0 +1,157 @@
+"""Device-resident octree container + split<->octree conversions.
+
+Mirrors the slice of ocnn.octree.Octree the reference touches on the sampling
+path with the same attribute / method names, and the reference's
+``create_full_octree`` (ldm_diffusion_util.py:318-325), ``split2octree_small`` /
+``split2octree_large`` (utils/util_dualoctree.py:225-273).  All per-node work
+(label extraction, split = exclusive scan, grow = key expansion) runs in
+libofx HIP kernels; only the per-depth node COUNTS come back to the host (they
+size the next allocation).
+"""
+import copy
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+
+class Octree:
+    def __init__(self, depth, full_depth=2, batch_size=1, device='cuda', **kwargs):
+        _lib.require_device()
+        self.depth = depth
+        self.full_depth = full_depth
+        self.batch_size = batch_size
+        self.device = torch.device(device)
+        n = depth + 1
+        self.keys = [None] * n
+        self.children = [None] * n
+        self.nnum = torch.zeros(n, dtype=torch.int64)          # host
+        self.nnum_nempty = torch.zeros(n, dtype=torch.int64)   # host
+
+    # ---- queries (ocnn API names) -------------------------------------
+    def nempty_mask(self, depth):
+        return self.children[depth] >= 0
+
+    def key(self, depth, nempty=False):
+        k = self.keys[depth]
+        return k[self.nempty_mask(depth)] if nempty else k
+
+    def batch_id(self, depth, nempty=False):
+        return self.key(depth, nempty) >> 48
+
+    def xyzb(self, depth, nempty=False):
+        # index plumbing for callers that want coordinates; the kernels decode keys themselves
+        k = self.key(depth, nempty)
+        b = k >> 48
+        k = k & ((1 << 48) - 1)
+        x = torch.zeros_like(k)
+        y = torch.zeros_like(k)
+        z = torch.zeros_like(k)
+        for i in range(depth):
+            x |= ((k >> (3 * i + 2)) & 1) << i
+            y |= ((k >> (3 * i + 1)) & 1) << i
+            z |= ((k >> (3 * i)) & 1) << i
+        return x, y, z, b
+
+    # ---- construction --------------------------------------------------
+    def octree_grow_full(self, depth, update_neigh=False):
+        n = (8 ** depth) * self.batch_size
+        self.keys[depth] = torch.empty(n, dtype=torch.int64, device=self.device)
+        self.children[depth] = torch.empty(n, dtype=torch.int32, device=self.device)
+        call('ofx_octree_full_layer', depth, self.batch_size, ptr(self.keys[depth]),
+             ptr(self.children[depth]), stream())
+        self.nnum[depth] = n
+        self.nnum_nempty[depth] = n
+
+    def octree_split(self, split, depth):
+        label = split.to(device=self.device, dtype=torch.int32).contiguous()
+        n = label.numel()
+        if n != int(self.nnum[depth]):
+            raise ValueError('octree_split: %d labels for %d nodes' % (n, int(self.nnum[depth])))
+        children = torch.empty(n, dtype=torch.int32, device=self.device)
+        scan = torch.empty(n + 1, dtype=torch.int32, device=self.device)
+        ws = torch.empty(_lib.lib().ofx_scan_ws_bytes(n), dtype=torch.uint8, device=self.device)
+        call('ofx_octree_split', ptr(label), n, ptr(children), ptr(scan), ptr(ws), stream())
+        self.children[depth] = children
+        self.nnum_nempty[depth] = int(scan[n].item())        # sizes the next layer (host sync)
+
+    def octree_grow(self, depth, update_neigh=False):
+        while len(self.keys) <= depth:
+            self.keys.append(None)
+            self.children.append(None)
+            self.nnum = torch.cat([self.nnum, torch.zeros(1, dtype=torch.int64)])
+            self.nnum_nempty = torch.cat([self.nnum_nempty, torch.zeros(1, dtype=torch.int64)])
+        n = int(self.nnum_nempty[depth - 1]) * 8
+        self.keys[depth] = torch.empty(n, dtype=torch.int64, device=self.device)
+        self.children[depth] = torch.empty(n, dtype=torch.int32, device=self.device)
+        call('ofx_octree_grow', ptr(self.keys[depth - 1]), ptr(self.children[depth - 1]),
+             int(self.nnum[depth - 1]), ptr(self.keys[depth]), ptr(self.children[depth]), stream())
+        self.nnum[depth] = n
+        self.nnum_nempty[depth] = n
+
+    def to(self, device):
+        return self
+
+    def cuda(self):
+        return self
+
+
+def create_full_octree(depth, full_depth, batch_size, device='cuda'):
+    """ldm_diffusion_util.py:318-325."""
+    octree = Octree(depth, full_depth, batch_size, device)
+    for d in range(full_depth + 1):
+        octree.octree_grow_full(d)
+    octree.depth = full_depth
+    return octree
+
+
+def split2octree_small(split, input_depth, full_depth):
+    """utils/util_dualoctree.py:225-250: [B, 8, S, S, S] split codes -> octree of depth full_depth+2."""
+    if not split.is_cuda:
+        raise _lib.OfxError('split2octree_small needs a HIP tensor (no CPU path)')
+    split = split.contiguous().float()
+    B = split.shape[0]
+    S = 1 << full_depth
+    if tuple(split.shape) != (B, 8, S, S, S):
+        raise ValueError('split must be [B, 8, %d, %d, %d]' % (S, S, S))
+    octree = create_full_octree(input_depth, full_depth, B, split.device)
+    n0 = int(octree.nnum[full_depth])
+    label0 = torch.empty(n0, dtype=torch.int32, device=split.device)
+    call('ofx_split_small_label0', ptr(split), B, full_depth, ptr(label0), stream())
+    octree.octree_split(label0, full_depth)
+    octree.octree_grow(full_depth + 1)
+    octree.depth += 1
+    label1 = torch.empty(int(octree.nnum[full_depth + 1]), dtype=torch.int32, device=split.device)
+    call('ofx_split_small_label1', ptr(split), B, full_depth, ptr(octree.children[full_depth]),
+         ptr(label1), stream())
+    octree.octree_split(label1, full_depth + 1)
+    octree.octree_grow(full_depth + 2)
+    octree.depth += 1
+    return octree
+
+
+def split2octree_large(octree, split, small_depth):
+    """utils/util_dualoctree.py:252-273: [nnum[small_depth], 8] split codes -> two more levels."""
+    if not split.is_cuda:
+        raise _lib.OfxError('split2octree_large needs a HIP tensor (no CPU path)')
+    split = split.contiguous().float()
+    n = int(octree.nnum[small_depth])
+    if tuple(split.shape) != (n, 8):
+        raise ValueError('split must be [%d, 8]' % n)
+    out = copy.copy(octree)
+    out.keys = list(octree.keys)
+    out.children = list(octree.children)
+    out.nnum = octree.nnum.clone()
+    out.nnum_nempty = octree.nnum_nempty.clone()
+    label0 = torch.empty(n, dtype=torch.int32, device=split.device)
+    call('ofx_split_large_label0', ptr(split), n, ptr(label0), stream())
+    out.octree_split(label0, small_depth)
+    out.octree_grow(small_depth + 1)
+    out.depth += 1
+    label1 = torch.empty(int(out.nnum[small_depth + 1]), dtype=torch.int32, device=split.device)
+    call('ofx_split_large_label1', ptr(split), n, ptr(out.children[small_depth]), ptr(label1), stream())
+    out.octree_split(label1, small_depth + 1)
+    out.octree_grow(small_depth + 2)
+    out.depth += 1
+    return out

@@ -1,0 +1,223 @@
+"""Tensor-level wrappers over the C ABI (include/ofx.h).
+
+Every function here launches hand-written HIP kernels from libofx.so on the
+current torch HIP stream.  Inputs must be CUDA (HIP) tensors; nothing here has
+a CPU implementation -- a CPU tensor raises.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+ACT = {None: 0, 'none': 0, 'silu': 1, 'gelu': 2}
+
+
+def _chk(t, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.OfxError('octfusion_amd ops need HIP tensors (no CPU path)')
+    if t.dtype != dtype:
+        raise TypeError('expected %s, got %s' % (dtype, t.dtype))
+
+
+def _row_major(t):
+    """(tensor, leading dimension) for a 2-D fp32 tensor whose rows are contiguous."""
+    _chk(t)
+    if t.dim() != 2:
+        raise ValueError('expected a 2-D tensor')
+    if t.stride(1) != 1 and t.shape[1] != 1:
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    if ld < t.shape[1]:
+        t = t.contiguous()
+        ld = t.shape[1]
+    return t, ld
+
+
+def scan_i32(x):
+    """Exclusive scan; returns int32 tensor of n+1 entries (last = total)."""
+    _chk(x, torch.int32)
+    n = x.numel()
+    out = torch.empty(n + 1, dtype=torch.int32, device=x.device)
+    ws = torch.empty(_lib.lib().ofx_scan_ws_bytes(n), dtype=torch.uint8, device=x.device)
+    call('ofx_scan_i32', ptr(x), ptr(out), n, ptr(ws), stream())
+    return out
+
+
+class PackedWeight:
+    """Weights re-laid-out once for the MFMA B tile ([k/4][n][4], k zero-padded to 32)."""
+
+    def __init__(self):
+        self.t = None
+        self.key = None
+        self.K = self.N = self.Kp = 0
+
+    def get(self, w, mode, cin=0, nt=0):
+        """mode 'kn': w is [K, N]; 'nk': w is [N, K] (nn.Linear); 'graphconv': [7*(cin+nt'), N]."""
+        key = (w.data_ptr(), w._version, tuple(w.shape), mode, cin, nt)
+        if key == self.key:
+            return self
+        _chk(w)
+        w = w.detach()
+        if not w.is_contiguous():
+            w = w.contiguous()
+        L = _lib.lib()
+        if mode == 'kn' or mode == 'graphconv':
+            K, N = w.shape
+            sk, sn = N, 1
+        elif mode == 'nk':
+            N, K = w.shape
+            sk, sn = 1, K
+        else:
+            raise ValueError(mode)
+        if mode == 'graphconv':
+            Kp = L.ofx_graphconv_packed_k(cin, nt)
+        else:
+            cin = nt = 0
+            Kp = L.ofx_packed_k(K)
+        out = torch.empty((Kp // 4) * N * 4, dtype=torch.float32, device=w.device)
+        call('ofx_pack_weights', ptr(w), sk, sn, K, N, cin, nt, ptr(out), Kp, stream())
+        self.t, self.key, self.K, self.N, self.Kp = out, key, K, N, Kp
+        return self
+
+
+def gemm(a, pw, bias=None, res=None, out=None, a_rows=None, out_rows=None, m=None):
+    """out[orow(i)] = a[arow(i)] @ W + bias + res[i] (fp32 MFMA)."""
+    a, lda = _row_major(a)
+    M = m if m is not None else (a_rows.numel() if a_rows is not None else a.shape[0])
+    if a.shape[1] != pw.K:
+        raise ValueError('K mismatch: %d vs %d' % (a.shape[1], pw.K))
+    if out is None:
+        out = torch.empty(M, pw.N, dtype=torch.float32, device=a.device)
+    out2, ldc = _row_major(out)
+    assert out2 is out, 'output must have contiguous rows'
+    ldr = 0
+    if res is not None:
+        res, ldr = _row_major(res)
+    _chk(bias)
+    _chk(a_rows, torch.int32)
+    _chk(out_rows, torch.int32)
+    call('ofx_gemm_f32', ptr(a), lda, ptr(a_rows), M, pw.K, ptr(pw.t), pw.Kp, pw.N, ptr(bias),
+         ptr(res), ldr, ptr(out), ldc, ptr(out_rows), stream())
+    return out
+
+
+def graphconv(x, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None, batch_id=None,
+              res=None, out=None):
+    """Fused dual-octree graph convolution (gather -> segment mean -> MFMA contraction)."""
+    x, ldx = _row_major(x)
+    N = x.shape[0]
+    if x.shape[1] != cin:
+        raise ValueError('cin mismatch')
+    if out is None:
+        out = torch.empty(N, pw.N, dtype=torch.float32, device=x.device)
+    out2, ldc = _row_major(out)
+    assert out2 is out
+    ldt = nt_pad = 0
+    if type_frac is not None:
+        _chk(type_frac)
+        ldt = type_frac.stride(0)
+        nt_pad = type_frac.shape[1]
+    lde = ldr = 0
+    if emb is not None:
+        emb, lde = _row_major(emb)
+        _chk(batch_id, torch.int32)
+    if res is not None:
+        res, ldr = _row_major(res)
+    _chk(bias)
+    call('ofx_graphconv_fwd', ptr(x), ldx, cin, N, ptr(seg_ptr), ptr(col), ptr(type_frac), ldt, nt_pad,
+         ptr(pw.t), pw.Kp, pw.N, ptr(bias), ptr(emb), lde, ptr(batch_id) if emb is not None else None,
+         ptr(res), ldr, ptr(out), ldc, stream())
+    return out
+
+
+def gather_mean(x, seg_ptr, col):
+    """col_data [N, 7, C]: the reference's scatter_mean(x[col], row*7+dir)."""
+    x, ldx = _row_major(x)
+    N, C = x.shape
+    out = torch.empty(N, 7, C, dtype=torch.float32, device=x.device)
+    call('ofx_gather_mean', ptr(x), ldx, C, N, ptr(seg_ptr), ptr(col), ptr(out), stream())
+    return out
+
+
+def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, act=None, out=None):
+    """DualOctreeGroupNorm (+ optional fused activation)."""
+    x, ldx = _row_major(x)
+    n, C = x.shape
+    dev = x.device
+    sums = torch.empty(batch_size * C * 2, dtype=torch.float64, device=dev)
+    mean = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
+    rstd = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
+    call('ofx_gn_stats', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
+    call('ofx_gn_finalize', ptr(sums), ptr(count), batch_size, C, groups, eps, ptr(mean), ptr(rstd), stream())
+    if out is None:
+        out = torch.empty(n, C, dtype=torch.float32, device=dev)
+    out2, ldo = _row_major(out)
+    assert out2 is out
+    w = weight.detach().reshape(-1)
+    b = bias.detach().reshape(-1)
+    call('ofx_gn_apply', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(w), ptr(b),
+         ACT[act], ptr(out), ldo, stream())
+    return out
+
+
+def rows_copy(src, dst, n, smap=None, dmap=None, C=None):
+    src, lds = _row_major(src)
+    dst2, ldd = _row_major(dst)
+    assert dst2 is dst
+    C = C if C is not None else src.shape[1]
+    call('ofx_rows_copy', ptr(src), lds, ptr(smap), ptr(dst), ldd, ptr(dmap), n, C, stream())
+    return dst
+
+
+def act(x, kind, out=None):
+    _chk(x)
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    call('ofx_act', ptr(x), ptr(out), x.numel(), ACT[kind], stream())
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    _chk(t)
+    t = t.contiguous()
+    out = torch.empty(t.shape[0], dim, dtype=torch.float32, device=t.device)
+    call('ofx_timestep_embedding', ptr(t), t.shape[0], dim, float(max_period), ptr(out), stream())
+    return out
+
+
+def octree2voxel_cf(data, batch_size, depth):
+    data, ld = _row_major(data)
+    C = data.shape[1]
+    S = 1 << depth
+    vox = torch.empty(batch_size, C, S, S, S, dtype=torch.float32, device=data.device)
+    call('ofx_octree2voxel_cf', ptr(data), ld, C, batch_size, depth, ptr(vox), stream())
+    return vox
+
+
+def voxel2octree_cf(vox, depth, out=None):
+    _chk(vox)
+    vox = vox.contiguous()
+    B, C = vox.shape[:2]
+    if out is None:
+        out = torch.empty(B * (8 ** depth), C, dtype=torch.float32, device=vox.device)
+    out2, ld = _row_major(out)
+    assert out2 is out
+    call('ofx_voxel2octree_cf', ptr(vox), C, B, depth, ptr(out), ld, stream())
+    return out
+
+
+def ddim_eps_update(x, eps, coef):
+    _chk(x), _chk(eps), _chk(coef)
+    assert x.is_contiguous() and eps.is_contiguous()
+    call('ofx_ddim_eps_update', ptr(x), ptr(eps), ptr(coef), x.numel(), stream())
+    return x
+
+
+def ddim_x0_update(x, x0, noise, coef):
+    _chk(x), _chk(x0), _chk(coef)
+    assert x.is_contiguous() and x0.is_contiguous()
+    call('ofx_ddim_x0_update', ptr(x), ptr(x0), ptr(noise), ptr(coef), x.numel(), stream())
+    return x

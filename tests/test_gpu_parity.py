@@ -1,0 +1,297 @@
+"""GPU parity: the HIP path (through the C ABI) against (a) golden vectors captured from
+the reference's own code and (b) the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for integer / index work (after canonical edge order); fp32 results within
+1e-3 relative (north_star) -- tested much tighter (2e-4) since the contraction is exact-fp32
+MFMA."""
+import pytest
+import torch
+
+import common as C
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+REL = 2e-4
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def close(a, b, rel=REL):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(float(b.abs().max()), 1e-6)
+    err = float((a - b).abs().max()) / scale
+    assert err < rel, 'rel-to-max error %.3e' % err
+
+
+def canon(edge_idx, edge_dir):
+    row, col = edge_idx[0].cpu(), edge_idx[1].cpu()
+    ed = edge_dir.cpu()
+    n = int(max(int(row.max()), int(col.max())) + 1)
+    order = torch.argsort((row * 7 + ed) * n + col, stable=True)
+    return torch.stack([row[order], col[order]]), ed[order]
+
+
+def check_octree(oc, rec):
+    assert oc.depth == rec['depth']
+    for d in range(oc.depth + 1):
+        assert int(oc.nnum[d]) == int(rec['nnum'][d])
+        assert int(oc.nnum_nempty[d]) == int(rec['nnum_nempty'][d])
+        assert torch.equal(oc.keys[d].cpu(), rec['keys'][d])
+        assert torch.equal(oc.children[d].cpu().long(), rec['children'][d].long())
+
+
+def check_doctree(doc, rec):
+    assert doc.total_num == rec['total_num']
+    assert torch.equal(doc.nnum, rec['nnum']) and torch.equal(doc.lnum, rec['lnum'])
+    assert torch.equal(doc.ncum, rec['ncum'])
+    for d, r in rec['graph'].items():
+        g = doc.graph[d]
+        assert bool((torch.diff(g['edge_idx'][0] * 7 + g['edge_dir']) >= 0).all())   # sort_edges order
+        ei, ed = canon(g['edge_idx'], g['edge_dir'])
+        assert ed.numel() == r['E'] and g['node_type'].numel() == r['N']
+        assert C.sha_int(ei) == r['sha_edge_idx']
+        assert C.sha_int(ed) == r['sha_edge_dir']
+        assert C.sha_int(g['node_type'].cpu()) == r['sha_node_type']
+        assert C.sha_int(g['keyd'].cpu()) == r['sha_keyd']
+        assert C.sha_int(g['node_mask'].cpu()) == r['sha_node_mask']
+        assert C.sha_int(doc.batch_id(d).cpu()) == r['sha_batch_id']
+        if 'edge_idx' in r:
+            assert torch.equal(ei, r['edge_idx'].long())
+
+
+def build(split, depth, fd):
+    from octfusion_amd.octree import split2octree_small
+    from octfusion_amd.dual_octree import DualOctree
+    oc = split2octree_small(split.to(dev()), depth, fd)
+    doc = DualOctree(oc)
+    doc.post_processing_for_docnn()
+    return oc, doc
+
+
+def tiny(split):
+    return build(split, 4, 2)
+
+
+def small(split):
+    return build(split, 5, 3)
+
+
+def load(module, keys):
+    sd = C.fill_state_dict(keys)
+    module.load_state_dict(sd, strict=True)
+    return module.to(dev()).eval()
+
+
+# ------------------------------------------------------------------ integer work
+def test_scan():
+    from octfusion_amd import ops
+    for n in [1, 7, 2048, 2049, 100000, 1 << 21]:
+        x = torch.randint(0, 5, (n,), dtype=torch.int32)
+        out = ops.scan_i32(x.to(dev())).cpu()
+        ref = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(x.long(), 0)])
+        assert torch.equal(out.long(), ref)
+
+
+def test_octree_and_graph_tiny(golden):
+    from octfusion_amd.octree import split2octree_large
+    from octfusion_amd.dual_octree import DualOctree
+    G = golden('g_octree_graph')
+    t = G['tiny']
+    oc, doc = tiny(t['split_small'])
+    check_octree(oc, t['octree'])
+    check_doctree(doc, t['doctree'])
+    tl = G['tiny_large']
+    oc_l = split2octree_large(oc, tl['split_large'].to(dev()), 4)
+    check_octree(oc_l, tl['octree'])
+    check_doctree(DualOctree(oc_l), tl['doctree'])
+
+
+def test_octree_and_graph_shell(golden):
+    from octfusion_amd.octree import split2octree_large
+    from octfusion_amd.dual_octree import DualOctree
+    G = golden('g_octree_graph')
+    s6 = G['shell6_b2']
+    oc, doc = build(C.shell6_split(2, jitter=True), 6, 4)
+    assert torch.equal(oc.nnum, s6['octree_nnum'])
+    for d in range(7):
+        assert C.sha_int(oc.keys[d].cpu()) == s6['sha_keys'][d]
+        assert C.sha_int(oc.children[d].cpu()) == s6['sha_children'][d]
+    check_doctree(doc, s6['doctree'])
+    s8 = G['shell8_b1']
+    oc6, _ = build(C.shell6_split(1), 6, 4)
+    x, y, z, b = oc6.xyzb(6)
+    oc8 = split2octree_large(oc6, C.shell8_split_large(x.cpu(), y.cpu(), z.cpu()).to(dev()), 6)
+    assert torch.equal(oc8.nnum, s8['octree_nnum'])
+    doc8 = DualOctree(oc8)
+    check_doctree(doc8, s8['doctree'])
+    assert doc8.csr(8)[2] == 448232 and doc8.csr(8)[3] == 3374048
+
+
+def test_graph_vs_oracle_random():
+    """Random ragged trees (incl. an all-empty batch element) against the CPU oracle."""
+    from oracle import dual_octree as OD, sampler as OS
+    for seed, B, p in [(21, 1, 0.2), (22, 3, 0.6), (23, 2, 0.05)]:
+        split = C.random_split_small(B, 2, seed, p=p)
+        if B == 3:
+            split[1] = -1.0                       # one element with nothing below the full layer
+        oc, doc = tiny(split)
+        o_oc = OS.split2octree_small(split, 4, 2)
+        o_doc = OD.OracleDualOctree(o_oc)
+        o_doc.post_processing_for_docnn()
+        for d in range(2, 5):
+            a = canon(doc.graph[d]['edge_idx'], doc.graph[d]['edge_dir'])
+            b = OD.canonical_edges(o_doc.graph[d]['edge_idx'], o_doc.graph[d]['edge_dir'])
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+            assert torch.equal(doc.graph[d]['node_type'].cpu(), o_doc.graph[d]['node_type'])
+            assert torch.equal(doc.graph[d]['keyd'].cpu(), o_doc.graph[d]['keyd'])
+            assert torch.equal(doc.graph[d]['node_mask'].cpu(), o_doc.graph[d]['node_mask'])
+            assert torch.equal(doc.batch_id(d).cpu(), o_doc.batch_id(d))
+
+
+def test_octree2voxel_roundtrip():
+    from octfusion_amd import ops
+    from oracle.octree import Octree, octree2voxel
+    for B, d, Cc in [(2, 2, 5), (1, 4, 64), (3, 3, 70)]:
+        data = torch.randn(B * 8 ** d, Cc)
+        oc = Octree(d, d, B)
+        for k in range(d + 1):
+            oc.octree_grow_full(k)
+        ref = octree2voxel(data, oc, d).permute(0, 4, 1, 2, 3).contiguous()
+        vox = ops.octree2voxel_cf(data.to(dev()), B, d)
+        assert torch.equal(vox.cpu(), ref)
+        back = ops.voxel2octree_cf(vox, d)
+        assert torch.equal(back.cpu(), data)
+
+
+# ------------------------------------------------------------------ fp32 modules vs golden
+def test_modules(golden):
+    from octfusion_amd import modules as M, ops
+    from oracle import modules as OM
+    G = golden('g_modules')
+    oc, doc = tiny(G['split_small'])
+    N4 = doc.csr(4)[2]
+    N3 = doc.csr(3)[2]
+
+    # stand-alone gather vs the reference's scatter_mean(x[col], row*7+dir)
+    x = C.rand_input('gm', N4, 12)
+    g = doc.graph[4]
+    idx = (g['edge_idx'][0] * 7 + g['edge_dir']).cpu()
+    ref = OM.scatter_mean(x[g['edge_idx'][1].cpu()], idx, N4 * 7)
+    got = ops.gather_mean(x.to(dev()), *doc.csr(4)[:2])
+    close(got.reshape(N4 * 7, 12), ref, 1e-6)
+
+    for name in ['gc_nt0', 'gc_nt3_bias', 'gc_d3', 'gc_c64']:
+        r = G[name]
+        cin, cout, et, deg, nt, bias = r['args']
+        m = load(M.GraphConv(cin, cout, et, deg, nt, use_bias=bias), r['keys'])
+        x = C.rand_input(name, doc.csr(r['d'])[2], cin).to(dev())
+        close(m(x, doc, r['d']), r['out'])
+    for name in ['gn12', 'gn64', 'gn60', 'gn96']:
+        r = G[name]
+        m = load(M.DualOctreeGroupNorm(r['c']), r['keys'])
+        assert m.group == r['group']
+        x = (C.rand_input(name, N4, r['c']) * 2 + 0.5).to(dev())
+        close(m(data=x, doctree=doc, depth=4), r['out'])
+    m = load(M.Downsample(6), G['down']['keys'])
+    close(m(C.rand_input('down', 40, 6).to(dev())), G['down']['out'])
+    m = load(M.Upsample(6), G['up']['keys'])
+    close(m(C.rand_input('up', 5, 6).to(dev())), G['up']['out'])
+    r = G['gdown']
+    m = load(M.GraphDownsample(*r['args']), r['keys'])
+    close(m(C.rand_input('gdown', N4, 8).to(dev()), doc, 4), r['out'])
+    r = G['gup']
+    m = load(M.GraphUpsample(*r['args']), r['keys'])
+    close(m(C.rand_input('gup', N3, 8).to(dev()), doc, 3), r['out'])
+    for name in ['rbe_diff', 'rbe_same']:
+        r = G[name]
+        m = load(M.GraphResBlockEmbed(*r['args']), r['keys'])
+        cin = r['args'][0]
+        y = m(C.rand_input(name, N4, cin).to(dev()), C.rand_input(name + 'e', 2, 32).to(dev()), doc, 4)
+        close(y, r['out'])
+    r = G['resblocks']
+    m = load(M.GraphResBlocks(*r['args']), r['keys'])
+    close(m(C.rand_input('resblocks', N4, 8).to(dev()), doc, 4), r['out'])
+    r = G['c1x1gngelu']
+    m = load(M.Conv1x1GnGeluSequential(8, 32), r['keys'])
+    close(m((C.rand_input('c1x1gngelu', N4, 8).to(dev()), doc, 4)), r['out'])
+
+
+def test_graphconv_wide_vs_oracle():
+    """MFMA fast path (cin % 32 == 0, several k-tiles and n-tiles, type slab, ragged M)."""
+    from octfusion_amd import modules as M
+    from oracle import dual_octree as OD, modules as OM, sampler as OS
+    split = C.random_split_small(2, 3, 31, p=0.45)
+    oc, doc = small(split)
+    o_oc = OS.split2octree_small(split, 5, 3)
+    o_doc = OD.OracleDualOctree(o_oc)
+    o_doc.post_processing_for_docnn()
+    for d, cin, cout, nt, bias in [(5, 64, 160, 4, True), (4, 128, 96, 3, False), (5, 32, 3, 4, False),
+                                   (3, 96, 130, 0, True)]:
+        m = M.GraphConv(cin, cout, 7, 7, nt, use_bias=bias)
+        keys = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        sd = C.fill_state_dict(keys)
+        m.load_state_dict(sd)
+        m = m.to(dev())
+        N = doc.csr(d)[2]
+        x = C.rand_input('wide%d' % d, N, cin)
+        ref = OM.graph_conv(x, o_doc, d, sd['weights'], sd.get('bias'), nt)
+        close(m(x.to(dev()), doc, d), ref)
+        # fused epilogue terms
+        emb = C.rand_input('wide_e', 2, cout)
+        res = C.rand_input('wide_r', N, cout)
+        ref2 = ref + emb[o_doc.batch_id(d)] + res
+        close(m(x.to(dev()), doc, d, emb=emb.to(dev()), res=res.to(dev())), ref2)
+
+
+def test_dense_and_unet(golden):
+    from octfusion_amd import graph_unet_lr as LR, graph_unet_union as U
+    G = golden('g_dense')
+    r = G['attn']
+    close(load(LR.AttentionBlock(32, num_heads=4), r['keys'])(r['x'].to(dev())), r['out'])
+    r = G['resnet']
+    close(load(LR.ResnetBlock(3, 8, 12, emb_dim=16, dropout=0.0), r['keys'])(r['x'].to(dev()), r['emb'].to(dev())),
+          r['out'])
+    r = G['lr']
+    lr = load(LR.UNet3DModel(**C.TINY_LR_CFG), r['keys'])
+    close(lr(x=r['x'].to(dev()), timesteps=r['t'].to(dev()), x_self_cond=r['x_self_cond'].to(dev())), r['out'], 1e-3)
+    oc, doc = small(G['split_small'])
+    m = G['lr_mid']
+    close(lr.forward_as_middle(m['h'].to(dev()), doc, m['t'].to(dev()), None, None), m['out'], 1e-3)
+
+    G = golden('g_unet')
+    oc, doc = small(G['split_small'])
+    for name in ['uncond', 'cond']:
+        r = G[name]
+        cfg = union_cfg(r['num_classes'])
+        net = load(U.UNet3DModel(**cfg), r['keys'])
+        label = r['label'].to(dev()) if r['label'] is not None else None
+        y = net(unet_type='hr', x=r['x'].to(dev()), doctree=doc, unet_lr=net.unet_lr,
+                timesteps=r['t'].to(dev()), x_self_cond=None, label=label)
+        close(y, r['out'], 1e-3)
+    from octfusion_amd.octree import split2octree_large
+    from octfusion_amd.dual_octree import DualOctree
+    r = G['feature']
+    oc_l = split2octree_large(oc, r['split_large'].to(dev()), 5)
+    doc_l = DualOctree(oc_l)
+    net = load(U.UNet3DModel(**r['cfg']), r['keys'])
+    y = net(unet_type='feature', x=r['x'].to(dev()), doctree=doc_l, unet_lr=net.unet_hr,
+            timesteps=r['t'].to(dev()), x_self_cond=None, label=None)
+    close(y, r['out'], 1e-3)
+
+
+def union_cfg(num_classes=None):
+    h, l = C.TINY_HR_CFG, C.TINY_LR_CFG
+    cfg = dict(stage_flag='hr', image_size=[8, 32], input_depth=[3, 5], unet_type=['lr', 'hr'],
+               full_depth=3, input_channels=[8, 3], out_channels=[8, 3],
+               model_channels=[l['model_channels'], h['model_channels']],
+               num_res_blocks=[[1, 1, 1], h['num_res_blocks']], attention_resolutions=[2, 4],
+               channel_mult=[l['channel_mult'], h['channel_mult']], num_heads=4,
+               use_checkpoint=False, dims=3)
+    if num_classes is not None:
+        cfg['num_classes'] = num_classes
+    return cfg

@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py -- denoising-steps/sec of OctFusion's stage-"hr" U-Net on MI355X.
+
+Workload (BASELINE.json configs[2], the one `metric` is quoted on): ShapeNet
+uncond "hr" stage (configs/octfusion_snet_uncond.yaml) on the synthetic
+shell-6 octree batch (diffusion depth 6 of the depth-8 VAE
+octree), batch 8 per GPU, DDIM eps-branch.  One step = one full U-Net forward
+(sparse hr net + the nested dense lr net) + the DDIM update for the whole batch.
+Inputs are resident in HBM before the timed region.  fp32 end to end.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def build_workload(dev, batch, config='snet_uncond'):
+    from octfusion_amd import configs, synthetic
+    from octfusion_amd.dual_octree import DualOctree
+    from octfusion_amd.graph_unet_union import UNet3DModel
+    from octfusion_amd.octree import split2octree_small
+    net = UNet3DModel(**configs.unet_params(config, 'hr'))
+    return net, synthetic.shell6_split(batch, jitter=True)
+
+
+def cpu_baseline(config, seconds=20.0):
+    """The reference's CPU path restated (oracle/), timed on this host's cores on a bounded
+    sample: B=1 shell-6 hr steps; scaled to the batch-8 unit by dividing by 8."""
+    from octfusion_amd import configs, synthetic
+    from octfusion_amd.graph_unet_union import UNet3DModel
+    from oracle import dual_octree as OD, modules as OM, sampler as OS, unet as OU
+    torch.set_num_threads(os.cpu_count())
+    net = UNet3DModel(**configs.unet_params(config, 'hr'))
+    sd = synthetic.random_state_dict(net)
+    parts = {p: OM._sub(sd, p) for p in ('unet_lr', 'unet_hr')}
+    st = configs.stage_cfgs(config)
+    oc = OS.split2octree_small(synthetic.shell6_split(1, jitter=False), 6, 4)
+    doc = OD.OracleDualOctree(oc)
+    doc.post_processing_for_docnn()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(doc.total_num, 3, generator=g)
+    times = OS.get_sampling_timesteps(1, 200)
+
+    def step(i, x):
+        t, tn = times[i]
+        ls, lsn = OS.beta_linear_log_snr(t), OS.beta_linear_log_snr(tn)
+        out = OU.hr_forward(parts['unet_hr'], st['hr'], x, doc, ls, None, parts['unet_lr'], st['lr'])
+        a, s = OS.log_snr_to_alpha_sigma(ls)
+        an, sn = OS.log_snr_to_alpha_sigma(lsn)
+        x0 = (x - out * s[0]) / a[0].clamp(min=1e-8)
+        return x0 * an[0] + out * sn[0]
+
+    with torch.no_grad():
+        x = step(0, x)                       # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            x = step(n + 1, x)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > seconds or n >= 50:
+                break
+    shape_steps = n / dt
+    return {'value': shape_steps / 8.0, 'unit': 'denoising-steps/sec (batch 8)', 'cores': os.cpu_count(),
+            'kind': 'port',
+            'sample': 'oracle (torch-CPU restatement of the reference op sequence), shell-6 B=1, '
+                      '%d timed steps in %.1f s after 1 warm-up; shape-steps/s / 8' % (n, dt)}
+
+
+def gather_microbench(doc, dev, C=128, iters=20):
+    """Stand-alone segment-mean gather (the reference's col_data) at depth 6: HBM GB/s."""
+    from octfusion_amd import ops
+    seg_ptr, col, N, E = doc.csr(6)
+    x = torch.randn(N, C, device=dev)
+    for _ in range(3):
+        ops.gather_mean(x, seg_ptr, col)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.gather_mean(x, seg_ptr, col)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = 4.0 * E * C + 8.0 * E + 4.0 * N * 7 * C          # SURVEY 8(d) stand-alone gather bytes
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {'kernel': 'gather_mean_kernel', 'C': C, 'N': N, 'E': E, 'ms': ms, 'achieved': gbs, 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='shapes per GPU (weak scaling)')
+    ap.add_argument('--config', default='snet_uncond')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    args = ap.parse_args()
+
+    from octfusion_amd import _lib, dist, ops, sampler, synthetic
+    from octfusion_amd.dual_octree import DualOctree
+    from octfusion_amd.octree import split2octree_small
+
+    rank, local_rank, world = dist.init()
+    if world != args.gpus:
+        if rank == 0:
+            print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    _lib.require_device()
+    torch.set_grad_enabled(False)
+    torch.backends.cudnn.benchmark = False
+
+    net, split = build_workload(dev, args.batch, args.config)
+    if rank == 0:
+        net.load_state_dict(synthetic.random_state_dict(net))
+    net = net.to(dev).eval()
+    bcast_bytes = dist.broadcast_module_(net, src=0)        # the only collective: weights, once
+
+    oc = split2octree_small(split.to(dev), 6, 4)
+    doc = DualOctree(oc)
+    N = doc.total_num
+    g = torch.Generator().manual_seed(1 + rank)
+    x = torch.randn(N, 3, generator=g).to(dev)
+    label = None
+    K, W = args.steps, args.warmup
+    times = sampler.sampling_times(200)
+    coefs = [sampler.eps_coef(t, tn).to(dev) for t, tn in times[:K + W]]
+    conds = [sampler.beta_linear_log_snr(t).float().expand(args.batch).contiguous().to(dev) for t, _ in times[:K + W]]
+
+    def step(i):
+        out = net(unet_type='hr', x=x, doctree=doc, unet_lr=net.unet_lr, timesteps=conds[i],
+                  x_self_cond=None, label=label)
+        ops.ddim_eps_update(x, out, coefs[i])
+
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize()
+    prof = []
+    ops.GRAPHCONV_PROFILE = prof
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    ops.GRAPHCONV_PROFILE = None
+    dt = dist.max_over_ranks(dt, dev)
+    assert torch.isfinite(x).all()
+
+    if rank == 0:
+        # dominant kernel: the fused GraphConv (gemm_kernel<MODE_GATHER,...>)
+        t_ms = sum(a.elapsed_time(b) for a, b, _, _ in prof)
+        flops = sum(f for _, _, f, _ in prof)
+        nbytes = sum(b for _, _, _, b in prof)
+        launches = len(prof)
+        ach = flops / (t_ms * 1e-3) / 1e12
+        roof = {'kernel': 'gemm_kernel<MODE_GATHER> (fused GraphConv, fp32 MFMA)', 'bound': 'mfma',
+                'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_F32_PEAK_TFLOPS,
+                'traffic': None, 'launches': launches, 'avg_launch_us': 1e3 * t_ms / max(launches, 1),
+                'flops_per_step': flops / K, 'algorithmic_bytes_per_step': nbytes / K,
+                'algorithmic_GBps': nbytes / (t_ms * 1e-3) / 1e9, 'time_frac_of_step': (t_ms * 1e-3) / dt}
+        res = {
+            'metric': 'denoising-steps/sec (depth-8 octree, batch 8)', 'value': world * K / dt,
+            'unit': 'steps/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': 1e3 * dt / K,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[2]: snet_uncond stage hr (+nested lr), shell-6 octree '
+                                   '(diffusion depth 6 of the depth-8 VAE octree), batch %d per GPU, DDIM eps step'
+                                   % args.batch,
+                       'config': args.config, 'batch_per_gpu': args.batch, 'nodes_per_gpu': N,
+                       'parallelism': 'batch-shard x%d, one RCCL weight broadcast (%d bytes)' % (world, bcast_bytes)},
+            'shape_steps_per_s': world * args.batch * K / dt,
+            'roofline': roof,
+            'gather': gather_microbench(doc, dev),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args.config, args.cpu_seconds)
+            res['gpu_over_cpu'] = res['value'] / res['cpu_baseline']['value']
+        print(json.dumps(res))
+    dist.barrier()
+
+
+if __name__ == '__main__':
+    main()

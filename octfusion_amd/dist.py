@@ -1,0 +1,74 @@
+"""One process per GPU: batch-shard of independent shapes + ONE weight broadcast.
+
+The reference samples independent shapes per rank and has every rank read the
+checkpoint from disk (train.py:166-185, octfusion_model_union.py:525-545).  Here
+rank 0 owns the weights and broadcasts them once, flattened into a single
+fp32 buffer, over RCCL/xGMI (132-335 MB: one large collective instead of one
+per tensor); there is no communication inside a denoising step.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'      # "nccl" is RCCL on ROCm
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_indices(n_items, rank, world):
+    """Rank r takes items {i : i mod world == r} -- the reference's rule (train.py:168)."""
+    return list(range(rank, n_items, world))
+
+
+@torch.no_grad()
+def broadcast_module_(module, src=0):
+    """Broadcast every parameter and buffer of `module` from `src` as ONE flat fp32 buffer."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    tensors = [t for t in tensors if t.is_floating_point()]
+    if not tensors:
+        return 0
+    dev = tensors[0].device
+    total = sum(t.numel() for t in tensors)
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    off = 0
+    if dist.get_rank() == src:
+        for t in tensors:
+            flat[off:off + t.numel()].copy_(t.reshape(-1))
+            off += t.numel()
+    dist.broadcast(flat, src=src)
+    off = 0
+    for t in tensors:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()
+    return total * 4
+
+
+def max_over_ranks(value, device):
+    """MAX all-reduce of a python float (timing)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -11,6 +11,10 @@ from ._lib import call, ptr, stream
 
 ACT = {None: 0, 'none': 0, 'silu': 1, 'gelu': 2}
 
+# bench.py sets this to a list to time every fused-GraphConv launch with HIP events on the
+# launching stream: entries are (start_event, end_event, algorithmic_flops, algorithmic_bytes).
+GRAPHCONV_PROFILE = None
+
 
 def _chk(t, dtype=torch.float32):
     if t is None:
@@ -126,9 +130,22 @@ def graphconv(x, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None, bat
     if res is not None:
         res, ldr = _row_major(res)
     _chk(bias)
+    prof = GRAPHCONV_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     call('ofx_graphconv_fwd', ptr(x), ldx, cin, N, ptr(seg_ptr), ptr(col), ptr(type_frac), ldt, nt_pad,
          ptr(pw.t), pw.Kp, pw.N, ptr(bias), ptr(emb), lde, ptr(batch_id) if emb is not None else None,
          ptr(res), ldr, ptr(out), ldc, stream())
+    if prof is not None:
+        e1.record()
+        E = col.numel()
+        k_logical = pw.K                                   # 7 * (cin + nt)
+        flops = 2.0 * N * k_logical * pw.N
+        # fused-op algorithmic bytes: one feature row per edge + output + weights + 8 B/edge
+        nbytes = 4.0 * (E * cin + N * pw.N + k_logical * pw.N) + 8.0 * E
+        prof.append((e0, e1, flops, nbytes))
     return out
 
 

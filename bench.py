@@ -44,7 +44,10 @@ def cpu_baseline(config, seconds=20.0):
     from octfusion_amd import configs, synthetic
     from octfusion_amd.graph_unet_union import UNet3DModel
     from oracle import dual_octree as OD, modules as OM, sampler as OS, unet as OU
-    torch.set_num_threads(os.cpu_count())
+    # torch-CPU scatter/index ops collapse when oversubscribed (256 threads: 140 s/step measured on
+    # the GPU box vs 1.7 s/step on 8 cores), so the baseline uses at most 32 threads -- stated in `cores`.
+    threads = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     net = UNet3DModel(**configs.unet_params(config, 'hr'))
     sd = synthetic.random_state_dict(net)
     parts = {p: OM._sub(sd, p) for p in ('unet_lr', 'unet_hr')}
@@ -66,16 +69,18 @@ def cpu_baseline(config, seconds=20.0):
         return x0 * an[0] + out * sn[0]
 
     with torch.no_grad():
+        tw = time.perf_counter()
         x = step(0, x)                       # warm-up
+        tw = time.perf_counter() - tw
         n, t0 = 0, time.perf_counter()
         while True:
             x = step(n + 1, x)
             n += 1
             dt = time.perf_counter() - t0
-            if dt > seconds or n >= 50:
+            if dt + tw > seconds or n >= 50:
                 break
     shape_steps = n / dt
-    return {'value': shape_steps / 8.0, 'unit': 'denoising-steps/sec (batch 8)', 'cores': os.cpu_count(),
+    return {'value': shape_steps / 8.0, 'unit': 'denoising-steps/sec (batch 8)', 'cores': threads,
             'kind': 'port',
             'sample': 'oracle (torch-CPU restatement of the reference op sequence), shell-6 B=1, '
                       '%d timed steps in %.1f s after 1 warm-up; shape-steps/s / 8' % (n, dt)}
@@ -109,7 +114,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='shapes per GPU (weak scaling)')
     ap.add_argument('--config', default='snet_uncond')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
     args = ap.parse_args()
 
     from octfusion_amd import _lib, dist, ops, sampler, synthetic
@@ -165,6 +170,15 @@ def main():
     dt = dist.max_over_ranks(dt, dev)
     assert torch.isfinite(x).all()
 
+    if rank == 0 and os.environ.get('OFX_BENCH_VERBOSE'):
+        agg = {}
+        for a, b, f, nb in prof:
+            k = (f, nb)
+            t, c = agg.get(k, (0.0, 0))
+            agg[k] = (t + a.elapsed_time(b), c + 1)
+        for (f, nb), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            print('conv flops %.3e bytes %.3e  n=%3d  avg %.3f ms  %.1f TF/s  %.0f GB/s' %
+                  (f, nb, c, t / c, f * c / t / 1e9, nb * c / t / 1e6), file=sys.stderr)
     if rank == 0:
         # dominant kernel: the fused GraphConv (gemm_kernel<MODE_GATHER,...>)
         t_ms = sum(a.elapsed_time(b) for a, b, _, _ in prof)

@@ -1,0 +1,58 @@
+"""World-size-2 gloo tests (CPU) of the multi-GPU path: shard rule, the single flattened weight
+broadcast, max-over-ranks timing."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from octfusion_amd import dist as D
+    r, lr, w = D.init(backend='gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)                        # ranks start with DIFFERENT weights
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
+    nbytes = D.broadcast_module_(net, src=0)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()] +
+                     [b.reshape(-1).float() for b in net.buffers() if b.is_floating_point()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], g) for g in gathered)
+    tmax = D.max_over_ranks(1.0 + rank, torch.device('cpu'))
+    D.barrier()
+    if rank == 0:
+        torch.save({'same': same, 'nbytes': nbytes, 'tmax': tmax, 'numel': flat.numel()}, out)
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_timing_world2(tmp_path):
+    out = str(tmp_path / 'r.pt')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r['same']
+    assert r['nbytes'] == 4 * r['numel']
+    assert r['tmax'] == 2.0
+
+
+def test_shard_rule():
+    sys.path.insert(0, ROOT)
+    from octfusion_amd.dist import shard_indices
+    items = [shard_indices(10, r, 4) for r in range(4)]
+    assert items[1] == [1, 5, 9]
+    assert sorted(sum(items, [])) == list(range(10))

@@ -131,6 +131,15 @@ int ofx_graph_fill(const ofx_tree_t* tree, int d, const int32_t* seg_ptr, int32_
 /* CSR -> the reference's COO view: row[e], dir[e] (int64) for edge_idx / edge_dir. */
 int ofx_graph_expand(const int32_t* seg_ptr, int64_t n_nodes, const int32_t* col,
                      int64_t* row_out, int64_t* col_out, int64_t* dir_out, void* stream);
+/* nbr[r*7+dir] = the single neighbour of segment (r,dir), -1 if none, -2 if several. */
+int ofx_graph_primary(const int32_t* seg_ptr, const int32_t* col, int64_t n_nodes, int32_t* nbr,
+                      void* stream);
+/* Extended table for the branch-free kernel: flag[s] = segment s has > 1 neighbours;
+ * with rank = exclusive scan of flag: nbr_ext[s] = neighbour id | N (none: zero row) |
+ * N + 1 + rank[s] (several: pre-averaged row), multi_seg[rank[s]] = s. */
+int ofx_graph_multi_flag(const int32_t* seg_ptr, int64_t n_nodes, int32_t* flag, void* stream);
+int ofx_graph_primary_ext(const int32_t* seg_ptr, const int32_t* col, int64_t n_nodes,
+                          const int32_t* rank, int32_t* nbr_ext, int32_t* multi_seg, void* stream);
 /* type_frac[r, dir*nt + t] = fraction of (r,dir)'s neighbours with node_type t; row
  * pitch ld floats, columns >= 7*nt zero-filled up to ld.  This is the one-hot
  * half of GraphConv's col_data (modules.py:199-210), constant per doctree. */
@@ -156,7 +165,7 @@ int ofx_pack_weights(const float* W, int64_t sk, int64_t sn, int64_t K, int64_t 
 int ofx_gemm_f32(const float* A, int64_t lda, const int32_t* a_rows, int64_t M, int64_t K,
                  const float* Wp, int64_t Kp, int64_t N, const float* bias,
                  const float* res, int64_t ldr, float* out, int64_t ldc,
-                 const int32_t* out_rows, void* stream);
+                 const int32_t* out_rows, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- GraphConv
  * Fused dual-octree graph convolution (modules.py:194-220 + scatter.py:42-66):
@@ -165,13 +174,47 @@ int ofx_gemm_f32(const float* A, int64_t lda, const int32_t* a_rows, int64_t M, 
  * The gather/segment-mean is done on the fly into LDS (col_data is never
  * written to HBM); the contraction runs on fp32 MFMA.  emb/batch_id fuse the
  * reference's per-batch-element time-embedding add (modules.py:754-758), res
- * the residual / skip add (:763).  type_frac may be NULL (nt <= 1). */
+ * the residual / skip add (:763).  type_frac may be NULL (nt <= 1).
+ * nbr = ofx_graph_primary table (generic path: any cin).  nbr_ext / multi_seg / aux
+ * (scratch of (n_multi+1)*cin floats) enable the branch-free fast path when
+ * cin % 32 == 0: a pre-pass averages the few multi-neighbour segments into aux, the
+ * main kernel then gathers exactly one row per (row,dir).  ws: split-K workspace. */
 int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes,
-                      const int32_t* seg_ptr, const int32_t* col,
+                      const int32_t* nbr, const int32_t* seg_ptr, const int32_t* col,
+                      const int32_t* nbr_ext, const int32_t* multi_seg, int64_t n_multi, float* aux,
                       const float* type_frac, int64_t ldt, int nt_pad,
                       const float* Wp, int64_t Kp, int cout, const float* bias,
                       const float* emb, int64_t lde, const int32_t* batch_id,
-                      const float* res, int64_t ldr, float* out, int64_t ldc, void* stream);
+                      const float* res, int64_t ldr, float* out, int64_t ldc,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- dense grids
+ * The nested dense U-Net (graph_unet_lr.py) in node-row layout: a full octree layer of
+ * depth d is rows b*8^d + morton(x,y,z), so octree2voxel / the gather back
+ * (graph_unet_lr.py:176-181) are identities and a 3x3x3 Conv3d is the same fused
+ * gather-GEMM with 27 taps.
+ * ofx_grid_conv_table: nbr27[row*27 + tap] (tap = (kx*3+ky)*3+kz); out-of-grid taps get
+ *   `pad`: -1 for the generic kernel, n_in (the zero row) for the branch-free kernel.
+ *   mode 0: nn.Conv3d(k3,p1) at depth_out; mode 1: ConvDownsample (k3,s2,p1,
+ *   modules.py:81-95) depth_out+1 -> depth_out; mode 2: ConvUpsample (nearest x2 then
+ *   k3,p1, modules.py:63-78) depth_out-1 -> depth_out.
+ * ofx_pack_conv3d: nn.Conv3d weight [cout,cin,3,3,3] -> packed k = tap*cin + c.
+ * ofx_gridconv_fwd: out[r,:] = sum_tap x[nbr27[r,tap],:] @ W_tap + bias + emb[bid[r]] + res[r]
+ *   (emb fuses ResnetBlock's time_mlp add, modules.py:507-511; res the skip, :513).
+ * ofx_attention: QKVAttention (modules.py:538-547) on rows; see csrc/ofx_dense.hip. */
+int ofx_grid_conv_table(int mode, int depth_out, int batch_size, int32_t pad, int32_t* nbr27,
+                        void* stream);
+int64_t ofx_conv3d_packed_k(int cin);
+int ofx_pack_conv3d(const float* W, int cin, int cout, float* Wp, void* stream);
+int ofx_gridconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_in, int64_t n_out,
+                     const int32_t* nbr27 /* pad -1, may be NULL */,
+                     const int32_t* nbr27_ext /* pad n_in, may be NULL */,
+                     const float* zero_row /* >= cin zeros, 16-B aligned */,
+                     const float* Wp, int cout, const float* bias, const float* emb, int64_t lde,
+                     const int32_t* batch_id, const float* res, int64_t ldr, float* out,
+                     int64_t ldc, void* ws, size_t ws_bytes, void* stream);
+int ofx_attention(const float* qkv, int64_t ldq, int batch_size, int T, int heads, int ch,
+                  float* out, int64_t ldo, void* stream);
 
 /* Stand-alone segment-mean gather: col_data[r, dir, :] (the reference's
  * `scatter_mean(x[col], row*7+dir)`, modules.py:208-210).  HBM-bound; used for
@@ -184,13 +227,14 @@ int ofx_gather_mean(const float* x, int64_t ldx, int cin, int64_t n_nodes,
  * DualOctreeGroupNorm (modules.py:291-326): statistics per (batch element,
  * group) over all nodes of that element.
  *  stats:    sums[b, c, 0..1] += (sum x, sum x^2) in fp64 (zeroed inside).
- *  finalize: mean/rstd [B, C] fp32 with the reference's inv_count =
- *            1/(count*cpg + eps) and centred variance.
+ *  finalize: mean/rstd [B, C] fp32 with inv_count = 1/(count*cpg + count_eps) and
+ *            centred variance; count_eps = eps reproduces the reference (:302),
+ *            count_eps = 0 is torch.nn.GroupNorm (GroupNorm32, modules.py:26-28).
  *  apply:    out = act((x - mean[b]) * rstd[b] * w + bias). */
 int ofx_gn_stats(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,
                  int batch_size, double* sums, void* stream);
 int ofx_gn_finalize(const double* sums, const float* count, int batch_size, int C, int groups,
-                    float eps, float* mean, float* rstd, void* stream);
+                    float eps, float count_eps, float* mean, float* rstd, void* stream);
 int ofx_gn_apply(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,
                  const float* mean, const float* rstd, const float* w, const float* bias,
                  int act, float* out, int64_t ldo, void* stream);

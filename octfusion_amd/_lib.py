@@ -51,12 +51,21 @@ _SIGS = {
     'ofx_packed_k': (c_l, [c_l], False),
     'ofx_graphconv_packed_k': (c_l, [c_i, c_i], False),
     'ofx_pack_weights': (c_i, [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_p, c_l, c_p], True),
-    'ofx_gemm_f32': (c_i, [c_p, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p], True),
-    'ofx_graphconv_fwd': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_l, c_i, c_p, c_l, c_i, c_p,
-                                c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p], True),
+    'ofx_gemm_f32': (c_i, [c_p, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_sz, c_p], True),
+    'ofx_graphconv_fwd': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l,
+                                c_i, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_sz, c_p], True),
+    'ofx_graph_multi_flag': (c_i, [c_p, c_l, c_p, c_p], True),
+    'ofx_graph_primary_ext': (c_i, [c_p, c_p, c_l, c_p, c_p, c_p, c_p], True),
+    'ofx_graph_primary': (c_i, [c_p, c_p, c_l, c_p, c_p], True),
+    'ofx_grid_conv_table': (c_i, [c_i, c_i, c_i, c_i, c_p, c_p], True),
+    'ofx_conv3d_packed_k': (c_l, [c_i], False),
+    'ofx_pack_conv3d': (c_i, [c_p, c_i, c_i, c_p, c_p], True),
+    'ofx_gridconv_fwd': (c_i, [c_p, c_l, c_i, c_l, c_l, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_p, c_p, c_l, c_p,
+                               c_l, c_p, c_sz, c_p], True),
+    'ofx_attention': (c_i, [c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_l, c_p], True),
     'ofx_gather_mean': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p], True),
     'ofx_gn_stats': (c_i, [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_p], True),
-    'ofx_gn_finalize': (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p], True),
+    'ofx_gn_finalize': (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p], True),
     'ofx_gn_apply': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p], True),
     'ofx_rows_copy': (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_p], True),
     'ofx_act': (c_i, [c_p, c_p, c_l, c_i, c_p], True),

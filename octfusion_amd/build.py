@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libofx.so')
-SOURCES = ['ofx_octree.hip', 'ofx_graph.hip', 'ofx_gemm.hip', 'ofx_norm.hip', 'ofx_misc.hip']
+SOURCES = ['ofx_octree.hip', 'ofx_graph.hip', 'ofx_gemm.hip', 'ofx_norm.hip', 'ofx_dense.hip', 'ofx_misc.hip']
 
 
 def _stale():

@@ -1,21 +1,26 @@
-// libofx: fp32-MFMA contraction core, dense GEMM and the fused dual-octree GraphConv.
+// libofx: fp32-MFMA contraction core: dense GEMM, the fused dual-octree GraphConv and the
+// dense-grid 3x3x3 convolution (same kernel, 27 "directions").
 //
 // One kernel template, two A-tile loaders:
-//   MODE_DENSE  : A[arow(m), k] row-major (optional row map)         -> ofx_gemm_f32
-//   MODE_GATHER : A[m, dir*cin + c] = mean_{e in seg(m,dir)} x[col[e], c], followed by
-//                 the dense node-type-fraction slab                   -> ofx_graphconv_fwd
-// The gathered [N, 7*cin] "col_data" of the reference (modules.py:208-210) never
-// exists in HBM: neighbour rows are fetched (16 B per lane, one 128-B line per
-// 8 lanes) straight into the LDS A-tile.
+//   MODE_DENSE  : A[arow(m), k] row-major (optional row map)                 -> ofx_gemm_f32
+//   MODE_GATHER : A[m, dir*cin + c] = x[nbr[m, dir], c]  (segment mean when a (row,dir)
+//                 has several neighbours), then the dense node-type-fraction slab
+//                                                      -> ofx_graphconv_fwd / ofx_gridconv_fwd
+// The gathered [N, ndir*cin] "col_data" of the reference (modules.py:208-210) never exists
+// in HBM: neighbour rows are fetched (16 B per lane, one 128-B line per 8 lanes) straight
+// into the LDS A-tile.  Neighbour indices are read once per (row, direction) -- not once per
+// k-tile -- and prefetched one direction ahead, so the k-loop carries no dependent loads.
 //
-// Tiling (wave = 64): block = 4 waves, BM = 128 rows, BK = 32; BN = 128 (2x2 waves of
-// 64x64) or BN = 32 (4x1 waves of 32x32) for narrow outputs.  Matrix core:
-// v_mfma_f32_32x32x2_f32 -- exact fp32 (k-ordered fma chain), 157 TF peak on gfx950;
-// parity with the fp32 reference is by construction, no reduced precision anywhere.
-// LDS: A tile [128][32+4] fp32 (pad 4 -> conflict-free ds_read_b128 over 16-lane
-// groups), B tile [8][BN][4] fp32 read as one ds_read_b128 per 4 k-steps; both double
-// buffered, one barrier per k-tile.  Weights are pre-packed once (ofx_pack_weights) to
-// [k/4][n][4] so the B tile is a straight 16-B-per-lane copy.
+// Tiling (wave = 64): block = 4 waves, BM = 128 rows, BK = 32; BN = 128 (2x2 waves of 64x64),
+// 64 (2x2 of 64x32) or 32 (4x1 of 32x32).  Matrix core: v_mfma_f32_32x32x2_f32 -- exact fp32
+// (k-ordered fma chain), 157 TF peak on gfx950; parity with the fp32 reference is by
+// construction.  LDS: A tile [128][32+4] fp32 (pad 4 -> conflict-free ds_read_b128 over the
+// 16-lane groups), B tile [8][BN][4] read as one ds_read_b128 per 4 k-steps; double buffered,
+// one barrier per k-tile.  Weights are pre-packed once (ofx_pack_weights / ofx_pack_conv3d)
+// to [k/4][n][4] so the B tile is a straight 16-B-per-lane copy.
+// Small-M problems (dense 4^3 / 8^3 grids) are split along K into up to 64 slices whose
+// partial tiles go to a workspace and are summed, in slice order (deterministic), by
+// splitk_reduce_kernel, which also applies the epilogue.
 #include "ofx_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -30,9 +35,12 @@ struct GemmArgs {
   // A (dense)
   const float* A; int64_t lda; const int32_t* a_rows;
   // A (gather)
-  const float* x; int64_t ldx; int cin; int fast;   // fast: cin % 32 == 0 and aligned
-  const int32_t* seg_ptr; const int32_t* col;
-  const float* tf; int64_t ldt; int64_t Kf;          // Kf = pad32(7*cin)
+  const float* x; int64_t ldx; int cin; int ndir; int fast;   // fast: cin % 32 == 0 and aligned
+  const int32_t* nbr;                                          // [M, ndir]: >=0 row, -1 none, -2 see CSR
+  const int32_t* seg_ptr; const int32_t* col;                  // CSR by segment m*ndir+dir (for -2 entries)
+  const float* tf; int64_t ldt; int64_t Kf;                    // Kf = pad32(ndir*cin)
+  const int32_t* nbr_ext;                                      // fast path: [M, ndir] in [0, n_src + 1 + V)
+  const float* aux; int64_t ldaux; int64_t n_src;              // aux row 0 = zeros, rows 1.. = multi-neighbour means
   // common
   int64_t M, K;            // K: logical K for dense bounds; gather uses Kp only
   const float* Wp; int64_t Kp, N;
@@ -40,94 +48,62 @@ struct GemmArgs {
   const float* emb; int64_t lde; const int32_t* bid;
   const float* res; int64_t ldr;
   float* out; int64_t ldc; const int32_t* out_rows;
-  int ntm, ntn;
+  int ntm, ntn, nsplit, kt_per_split;
+  float* ws;               // split-K partials [nsplit][M][N]
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void f4add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
-// scalar (slow-path) gathered element: mean over segment (row, dir) of x[col, c]
-__device__ __forceinline__ float gather_elem(const GemmArgs& g, int64_t row, int64_t k) {
-  if (k >= 7 * (int64_t)g.cin) return 0.f;
-  const int dir = (int)(k / g.cin), c = (int)(k - (int64_t)dir * g.cin);
-  const int32_t s = g.seg_ptr[row * 7 + dir], e = g.seg_ptr[row * 7 + dir + 1];
-  float acc = 0.f;
-  for (int32_t p = s; p < e; ++p) acc += g.x[(int64_t)g.col[p] * g.ldx + c];
-  if (e - s > 1) acc /= (float)(e - s);
+// mean over the CSR segment (row, dir) of x[col, cc..cc+3]
+__device__ __forceinline__ float4 gather_seg4(const GemmArgs& g, int64_t row, int dir, int cc) {
+  const int64_t s = row * g.ndir + dir;
+  const int32_t a = g.seg_ptr[s], e = g.seg_ptr[s + 1];
+  float4 acc = f4zero();
+  for (int32_t p = a; p < e; ++p) f4add(acc, *reinterpret_cast<const float4*>(g.x + (int64_t)g.col[p] * g.ldx + cc));
+  if (e - a > 1) {
+    const float inv = 1.f / (float)(e - a);
+    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+  }
   return acc;
 }
 
-template <int MODE>
-__device__ __forceinline__ void load_a_tile(const GemmArgs& g, int64_t m0, int64_t k0, float4 (&va)[4]) {
+// scalar (slow-path) gathered element
+__device__ __forceinline__ float gather_elem(const GemmArgs& g, int64_t row, int64_t k) {
+  if (k >= (int64_t)g.ndir * g.cin) return 0.f;
+  const int dir = (int)(k / g.cin), c = (int)(k - (int64_t)dir * g.cin);
+  const int32_t nb = g.nbr[row * g.ndir + dir];
+  if (nb >= 0) return g.x[(int64_t)nb * g.ldx + c];
+  if (nb == -1) return 0.f;
+  const int64_t s = row * g.ndir + dir;
+  const int32_t a = g.seg_ptr[s], e = g.seg_ptr[s + 1];
+  float acc = 0.f;
+  for (int32_t p = a; p < e; ++p) acc += g.x[(int64_t)g.col[p] * g.ldx + c];
+  if (e - a > 1) acc /= (float)(e - a);
+  return acc;
+}
+
+__device__ __forceinline__ void load_a_dense(const GemmArgs& g, int64_t m0, int64_t k0, float4 (&va)[4]) {
   const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
-  if (MODE == MODE_DENSE) {
-    const int64_t k = k0 + c4 * 4;
-    const bool vec = ((g.lda & 3) == 0) && (k + 3 < g.K) && ((((uintptr_t)g.A) & 15) == 0);
+  const int64_t k = k0 + c4 * 4;
+  const bool vec = ((g.lda & 3) == 0) && (k + 3 < g.K) && ((((uintptr_t)g.A) & 15) == 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t m = m0 + r0 + 32 * i;
-      float4 v = f4zero();
-      if (m < g.M) {
-        const int64_t ar = g.a_rows ? (int64_t)g.a_rows[m] : m;
-        const float* p = g.A + ar * g.lda + k;
-        if (vec) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (k + 0 < g.K) v.x = p[0];
-          if (k + 1 < g.K) v.y = p[1];
-          if (k + 2 < g.K) v.z = p[2];
-          if (k + 3 < g.K) v.w = p[3];
-        }
-      }
-      va[i] = v;
-    }
-  } else {
-    if (k0 >= g.Kf) {                                  // node-type fraction slab (dense, zero padded)
-      const int64_t kt = k0 - g.Kf + c4 * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + r0 + 32 * i;
-        va[i] = (m < g.M) ? *reinterpret_cast<const float4*>(g.tf + m * g.ldt + kt) : f4zero();
-      }
-    } else if (g.fast) {
-      const int dir = (int)(k0 / g.cin);
-      const int cc = (int)(k0 - (int64_t)dir * g.cin) + c4 * 4;
-      int32_t s[4], e[4], c[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + r0 + 32 * i;
-        s[i] = 0; e[i] = 0;
-        if (m < g.M) { s[i] = g.seg_ptr[m * 7 + dir]; e[i] = g.seg_ptr[m * 7 + dir + 1]; }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) c[i] = e[i] > s[i] ? g.col[s[i]] : -1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        va[i] = c[i] >= 0 ? *reinterpret_cast<const float4*>(g.x + (int64_t)c[i] * g.ldx + cc) : f4zero();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (e[i] - s[i] > 1) {                           // coarse leaf touching several finer nodes (rare)
-          for (int32_t p = s[i] + 1; p < e[i]; ++p)
-            f4add(va[i], *reinterpret_cast<const float4*>(g.x + (int64_t)g.col[p] * g.ldx + cc));
-          const float inv = 1.f / (float)(e[i] - s[i]);
-          va[i].x *= inv; va[i].y *= inv; va[i].z *= inv; va[i].w *= inv;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + r0 + 32 * i;
-        float4 v = f4zero();
-        if (m < g.M) {
-          const int64_t k = k0 + c4 * 4;
-          v.x = gather_elem(g, m, k);
-          v.y = gather_elem(g, m, k + 1);
-          v.z = gather_elem(g, m, k + 2);
-          v.w = gather_elem(g, m, k + 3);
-        }
-        va[i] = v;
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + r0 + 32 * i;
+    float4 v = f4zero();
+    if (m < g.M) {
+      const int64_t ar = g.a_rows ? (int64_t)g.a_rows[m] : m;
+      const float* p = g.A + ar * g.lda + k;
+      if (vec) {
+        v = *reinterpret_cast<const float4*>(p);
+      } else {
+        if (k + 0 < g.K) v.x = p[0];
+        if (k + 1 < g.K) v.y = p[1];
+        if (k + 2 < g.K) v.z = p[2];
+        if (k + 3 < g.K) v.w = p[3];
       }
     }
+    va[i] = v;
   }
 }
 
@@ -153,18 +129,22 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
 
   // XCD-aware tile order: consecutive tiles (which share gathered neighbour rows through
   // Morton locality) stay on one XCD / one L2.  Bijective for any grid size.
-  const int nblk = g.ntm * g.ntn;
+  const int ntile = g.ntm * g.ntn;
+  const int nblk = ntile * g.nsplit;
   int bid = blockIdx.x;
   {
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, j = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
+  const int split = bid / ntile;
+  bid -= split * ntile;
   const int tm = bid / g.ntn, tn = bid - tm * g.ntn;
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int l31 = lane & 31, h = lane >> 5;
+  const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -176,8 +156,68 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
 
   float4 va[4];
   float4 vb[BN / 32];
-  const int nkt = (int)(g.Kp / BK);
-  const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  const int nkt_all = (int)(g.Kp / BK);
+  const int kt_begin = split * g.kt_per_split;
+  const int kt_end = (kt_begin + g.kt_per_split < nkt_all) ? kt_begin + g.kt_per_split : nkt_all;
+
+  // gather state: neighbour ids of this thread's 4 rows for the current direction and the next one
+  int32_t nb[4] = {-1, -1, -1, -1}, nbn[4] = {-1, -1, -1, -1};
+  int dir_cur = -1, dir_next = -1;
+  auto load_nbr = [&](int dir, int32_t (&dst)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + r0 + 32 * i;
+      dst[i] = (m < g.M && dir < g.ndir) ? g.nbr[m * g.ndir + dir] : -1;
+    }
+  };
+
+  auto load_a = [&](int kt) {
+    const int64_t k0 = (int64_t)kt * BK;
+    if (MODE == MODE_DENSE) {
+      load_a_dense(g, m0, k0, va);
+    } else if (k0 >= g.Kf) {                               // node-type fraction slab (dense, zero padded)
+      const int64_t kk = k0 - g.Kf + c4 * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + r0 + 32 * i;
+        va[i] = (m < g.M) ? *reinterpret_cast<const float4*>(g.tf + m * g.ldt + kk) : f4zero();
+      }
+    } else if (g.fast) {
+      const int dir = (int)(k0 / g.cin);
+      const int cc = (int)(k0 - (int64_t)dir * g.cin) + c4 * 4;
+      if (dir != dir_cur) {
+        if (dir == dir_next) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) nb[i] = nbn[i];
+        } else {
+          load_nbr(dir, nb);
+        }
+        dir_cur = dir;
+        dir_next = dir + 1;
+        load_nbr(dir_next, nbn);                             // prefetch: consumed >= cin/32 k-tiles later
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        va[i] = nb[i] >= 0 ? *reinterpret_cast<const float4*>(g.x + (int64_t)nb[i] * g.ldx + cc) : f4zero();
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (nb[i] == -2) va[i] = gather_seg4(g, m0 + r0 + 32 * i, dir, cc);   // several neighbours (rare)
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + r0 + 32 * i;
+        float4 v = f4zero();
+        if (m < g.M) {
+          const int64_t k = k0 + c4 * 4;
+          v.x = gather_elem(g, m, k);
+          v.y = gather_elem(g, m, k + 1);
+          v.z = gather_elem(g, m, k + 2);
+          v.w = gather_elem(g, m, k + 3);
+        }
+        va[i] = v;
+      }
+    }
+  };
 
   auto store_tiles = [&](int buf) {
     float* a = As + buf * BM * A_LD;
@@ -188,15 +228,17 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
     for (int i = 0; i < BN / 32; ++i) *reinterpret_cast<float4*>(b + (threadIdx.x + 256 * i) * 4) = vb[i];
   };
 
-  load_a_tile<MODE>(g, m0, 0, va);
-  load_b_tile<BN>(g, n0, 0, vb);
-  store_tiles(0);
+  if (kt_begin < kt_end) {
+    load_a(kt_begin);
+    load_b_tile<BN>(g, n0, (int64_t)kt_begin * BK, vb);
+    store_tiles(0);
+  }
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) {
-      load_a_tile<MODE>(g, m0, (int64_t)(kt + 1) * BK, va);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    if (kt + 1 < kt_end) {
+      load_a(kt + 1);
       load_b_tile<BN>(g, n0, (int64_t)(kt + 1) * BK, vb);
     }
     const float* a = As + buf * BM * A_LD + (wm * MI * 32 + l31) * A_LD + h * 16;
@@ -218,7 +260,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nkt) store_tiles(buf ^ 1);
+    if (kt + 1 < kt_end) store_tiles(buf ^ 1);
     __syncthreads();
   }
 
@@ -229,6 +271,14 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
     for (int j = 0; j < NI; ++j) {
       const int64_t n = n0 + (wn * NI + j) * 32 + l31;
       if (n >= g.N) continue;
+      if (g.nsplit > 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < g.M) g.ws[((int64_t)split * g.M + m) * g.N + n] = acc[i][j][r];
+        }
+        continue;
+      }
       const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -245,26 +295,375 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
   }
 }
 
-template <int MODE>
-static int launch_gemm(GemmArgs& g, hipStream_t st) {
-  g.ntm = (int)ofx_cdiv(g.M, BM);
-  if (g.M <= 0 || g.N <= 0) return OFX_OK;
-  if (g.N <= 32) {
-    g.ntn = (int)ofx_cdiv(g.N, 32);
-    constexpr size_t lds = (2 * BM * A_LD + 2 * 8 * 32 * 4) * sizeof(float);
-    gemm_kernel<MODE, 4, 1, 1, 1><<<g.ntm * g.ntn, 256, lds, st>>>(g);
-  } else {
-    g.ntn = (int)ofx_cdiv(g.N, 128);
-    constexpr size_t lds = (2 * BM * A_LD + 2 * 8 * 128 * 4) * sizeof(float);   // 68 KB > 64 KB default cap
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, 2, 2, 2, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return OFX_ELAUNCH;
-      attr_set = true;
+
+// ---------------------------------------------------------------------------------
+// Fast gather kernel: cin % 32 == 0, 16-B aligned rows, extended neighbour table.
+// The loader is branch-free so the compiler keeps the gathers in flight across the MFMA
+// block (the generic kernel's control flow forces s_waitcnt vmcnt(0) before the MFMAs):
+//   * nbr_ext[m, dir] always names a source row: < n_src -> x, n_src -> the zero row of
+//     `aux` (no neighbour / zero padding), > n_src -> a pre-averaged row of `aux`
+//     (segment with several neighbours, written by multi_mean_kernel);
+//   * indices for tile t are loaded two iterations ahead (L1 hits: they only change when
+//     the direction changes), the rows for tile t one iteration ahead;
+//   * tile rows / columns past M / N are clamped, never branched on (their accumulators
+//     are simply not stored);
+//   * the node-type slab is the same code with (base, row, pitch) = (tf, m, ldt).
+// MFMA operand fragments are double-buffered in registers across the 4 k-quads.
+// pin a wave-uniform 64-bit value in SGPRs and make it opaque (stops hipcc from re-deriving it as a
+// per-lane load from the kernarg segment, which it does for `cond ? g.a : g.b` on by-value structs)
+__device__ __forceinline__ uint64_t sgpr64(uint64_t v) {
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// global-address-space views: pointers rebuilt from integers are "generic" to hipcc, which then emits
+// flat_load (counted on BOTH vmcnt and lgkmcnt -> every LDS wait would also wait for the gathers).
+typedef const float __attribute__((address_space(1)))* gfp;
+typedef const int32_t __attribute__((address_space(1)))* gip;
+__device__ __forceinline__ float4 ldg4(gfp p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = *reinterpret_cast<const v4f __attribute__((address_space(1)))*>(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void mfma_tile(const float* __restrict__ a, const float* __restrict__ b, f32x16 (&acc)[MI][NI]) {
+  constexpr int BN = WN * NI * 32;
+  float4 fa[2][MI], fb[2][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) fa[0][i] = *reinterpret_cast<const float4*>(a + i * 32 * A_LD);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) fb[0][j] = *reinterpret_cast<const float4*>(b + (j * 32) * 4);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cur = q & 1, nxt = cur ^ 1;
+    if (q < 3) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[nxt][i] = *reinterpret_cast<const float4*>(a + i * 32 * A_LD + (q + 1) * 4);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[nxt][j] = *reinterpret_cast<const float4*>(b + ((q + 1) * BN + j * 32) * 4);
     }
-    gemm_kernel<MODE, 2, 2, 2, 2><<<g.ntm * g.ntn, 256, lds, st>>>(g);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
+      }
   }
+}
+
+// element offset (from x) of source row `id`: rows >= n_src live in aux (same row pitch ldx);
+// pure ALU (no select on pointers) so hipcc cannot turn it into a branch or a kernarg re-load.
+__device__ __forceinline__ int64_t src_off(int32_t id, int64_t ldx, int64_t n_src, int64_t aux_delta) {
+  const int64_t i = id;
+  const int64_t mask = (n_src - 1 - i) >> 63;           // all ones iff id >= n_src
+  return i * ldx + (aux_delta & mask);
+}
+
+template <int WM, int WN, int MI, int NI>
+__global__ void __launch_bounds__(256, 2) gather_gemm_fast_kernel(const GemmArgs g) {
+  constexpr int BN = WN * NI * 32;
+  constexpr int NB = BN / 32;
+  static_assert(WM * MI * 32 == BM, "BM");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * BM * A_LD;
+
+  const int ntile = g.ntm * g.ntn;
+  const int nblk = ntile * g.nsplit;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, j = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int split = bid / ntile;
+  bid -= split * ntile;
+  const int tm = bid / g.ntn, tn = bid - tm * g.ntn;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+
+  // wave-uniform operands, pinned in SGPRs
+  const gfp xp = (gfp)sgpr64((uint64_t)g.x);
+  const gfp tfp = (gfp)sgpr64((uint64_t)g.tf);
+  const gfp wp = (gfp)sgpr64((uint64_t)g.Wp);
+  const gip tab = (gip)sgpr64((uint64_t)g.nbr_ext);
+  const int64_t ldx = (int64_t)sgpr64((uint64_t)g.ldx);
+  const int64_t ldt = (int64_t)sgpr64((uint64_t)g.ldt), n_src = (int64_t)sgpr64((uint64_t)g.n_src);
+  const int64_t Ncols = (int64_t)sgpr64((uint64_t)g.N);
+  const int64_t aux_delta = (int64_t)sgpr64((uint64_t)((g.aux - g.x) - g.n_src * g.ldx));
+  const int ndir = g.ndir;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nkt_all = (int)(g.Kp / BK);
+  const int kt_begin = split * g.kt_per_split;
+  const int kt_end = (kt_begin + g.kt_per_split < nkt_all) ? kt_begin + g.kt_per_split : nkt_all;
+  const int tpd = g.cin / BK;                    // k-tiles per direction
+  const int nkt_g = ndir * tpd;                  // gather tiles; tiles beyond are the type slab
+  const int g_begin = kt_begin < nkt_g ? kt_begin : nkt_g;
+  const int g_end = kt_end < nkt_g ? kt_end : nkt_g;
+  const int t_begin = kt_begin > nkt_g ? kt_begin : nkt_g;
+
+  // per-thread constants (rows / columns clamped: tiles past M / N are computed but never stored)
+  int64_t m_0 = m0 + r0, m_1 = m_0 + 32, m_2 = m_0 + 64, m_3 = m_0 + 96;
+  const int64_t mmax = g.M - 1;
+  m_0 = m_0 < mmax ? m_0 : mmax; m_1 = m_1 < mmax ? m_1 : mmax;
+  m_2 = m_2 < mmax ? m_2 : mmax; m_3 = m_3 < mmax ? m_3 : mmax;
+  const gip t0 = tab + m_0 * ndir;
+  const gip t1 = tab + m_1 * ndir;
+  const gip t2 = tab + m_2 * ndir;
+  const gip t3 = tab + m_3 * ndir;
+  int64_t bo0 = 0, bo1 = 0, bo2 = 0, bo3 = 0;
+  {
+    auto boff = [&](int i) {
+      const int idx = threadIdx.x + 256 * i;
+      int64_t nn = n0 + idx % BN;
+      nn = nn < Ncols ? nn : Ncols - 1;
+      return ((int64_t)(idx / BN) * Ncols + nn) * 4;
+    };
+    bo0 = boff(0);
+    if (NB > 1) bo1 = boff(1);
+    if (NB > 2) { bo2 = boff(2); bo3 = boff(3); }
+  }
+  float* const a_st = As + r0 * A_LD + c4 * 4;
+  float* const b_st = Bs + threadIdx.x * 4;
+  const float* const a_ld = As + (wm * MI * 32 + l31) * A_LD + h * 16;
+  const float* const b_ld = Bs + ((h * 4) * BN + wn * NI * 32 + l31) * 4;
+
+  float4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
+  vb1 = vb2 = vb3 = f4zero();
+
+  // ------------------------------------------------------------ gather tiles
+  if (g_begin < g_end) {
+    int32_t ia0, ia1, ia2, ia3, ib0, ib1, ib2, ib3;
+    {
+      const int d0 = g_begin / tpd;
+      const int d1c = (g_begin + 1) / tpd;
+      const int d1 = d1c < ndir ? d1c : ndir - 1;
+      ia0 = t0[d0]; ia1 = t1[d0]; ia2 = t2[d0]; ia3 = t3[d0];
+      ib0 = t0[d1]; ib1 = t1[d1]; ib2 = t2[d1]; ib3 = t3[d1];
+      const int cc = (g_begin - d0 * tpd) * BK + c4 * 4;
+      va0 = ldg4(xp + src_off(ia0, ldx, n_src, aux_delta) + cc);
+      va1 = ldg4(xp + src_off(ia1, ldx, n_src, aux_delta) + cc);
+      va2 = ldg4(xp + src_off(ia2, ldx, n_src, aux_delta) + cc);
+      va3 = ldg4(xp + src_off(ia3, ldx, n_src, aux_delta) + cc);
+      const gfp wk = wp + (int64_t)g_begin * 8 * Ncols * 4;
+      vb0 = ldg4(wk + bo0);
+      if (NB > 1) vb1 = ldg4(wk + bo1);
+      if (NB > 2) { vb2 = ldg4(wk + bo2); vb3 = ldg4(wk + bo3); }
+    }
+    *reinterpret_cast<float4*>(a_st) = va0;
+    *reinterpret_cast<float4*>(a_st + 32 * A_LD) = va1;
+    *reinterpret_cast<float4*>(a_st + 64 * A_LD) = va2;
+    *reinterpret_cast<float4*>(a_st + 96 * A_LD) = va3;
+    *reinterpret_cast<float4*>(b_st) = vb0;
+    if (NB > 1) *reinterpret_cast<float4*>(b_st + 1024) = vb1;
+    if (NB > 2) { *reinterpret_cast<float4*>(b_st + 2048) = vb2; *reinterpret_cast<float4*>(b_st + 3072) = vb3; }
+    ia0 = ib0; ia1 = ib1; ia2 = ib2; ia3 = ib3;
+    __syncthreads();
+
+    for (int kt = g_begin; kt < g_end; ++kt) {
+      const int buf = (kt - g_begin) & 1;
+      // prefetch: indices of tile kt+2, rows + weights of tile kt+1 (clamped at the last gather tile)
+      const int ktn = kt + 1 < nkt_g ? kt + 1 : nkt_g - 1;
+      const int dn = ktn / tpd;
+      const int d2c = (kt + 2) / tpd;
+      const int d2 = d2c < ndir ? d2c : ndir - 1;
+      ib0 = t0[d2]; ib1 = t1[d2]; ib2 = t2[d2]; ib3 = t3[d2];
+      const int cc = (ktn - dn * tpd) * BK + c4 * 4;
+      va0 = ldg4(xp + src_off(ia0, ldx, n_src, aux_delta) + cc);
+      va1 = ldg4(xp + src_off(ia1, ldx, n_src, aux_delta) + cc);
+      va2 = ldg4(xp + src_off(ia2, ldx, n_src, aux_delta) + cc);
+      va3 = ldg4(xp + src_off(ia3, ldx, n_src, aux_delta) + cc);
+      const gfp wk = wp + (int64_t)ktn * 8 * Ncols * 4;
+      vb0 = ldg4(wk + bo0);
+      if (NB > 1) vb1 = ldg4(wk + bo1);
+      if (NB > 2) { vb2 = ldg4(wk + bo2); vb3 = ldg4(wk + bo3); }
+      // pin the issue order: hipcc otherwise sinks these loads below the MFMA block (shorter live
+      // ranges), which exposes the whole gather latency every k-tile.
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_tile<WM, WN, MI, NI>(a_ld + buf * BM * A_LD, b_ld + buf * 8 * BN * 4, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      float* as = a_st + (buf ^ 1) * BM * A_LD;
+      float* bs = b_st + (buf ^ 1) * 8 * BN * 4;
+      *reinterpret_cast<float4*>(as) = va0;
+      *reinterpret_cast<float4*>(as + 32 * A_LD) = va1;
+      *reinterpret_cast<float4*>(as + 64 * A_LD) = va2;
+      *reinterpret_cast<float4*>(as + 96 * A_LD) = va3;
+      *reinterpret_cast<float4*>(bs) = vb0;
+      if (NB > 1) *reinterpret_cast<float4*>(bs + 1024) = vb1;
+      if (NB > 2) { *reinterpret_cast<float4*>(bs + 2048) = vb2; *reinterpret_cast<float4*>(bs + 3072) = vb3; }
+      ia0 = ib0; ia1 = ib1; ia2 = ib2; ia3 = ib3;
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------ node-type slab tiles (dense rows of tf)
+  for (int kt = t_begin; kt < kt_end; ++kt) {
+    const int cc = (kt - nkt_g) * BK + c4 * 4;
+    va0 = ldg4(tfp + m_0 * ldt + cc);
+    va1 = ldg4(tfp + m_1 * ldt + cc);
+    va2 = ldg4(tfp + m_2 * ldt + cc);
+    va3 = ldg4(tfp + m_3 * ldt + cc);
+    const gfp wk = wp + (int64_t)kt * 8 * Ncols * 4;
+    vb0 = ldg4(wk + bo0);
+    if (NB > 1) vb1 = ldg4(wk + bo1);
+    if (NB > 2) { vb2 = ldg4(wk + bo2); vb3 = ldg4(wk + bo3); }
+    *reinterpret_cast<float4*>(a_st) = va0;
+    *reinterpret_cast<float4*>(a_st + 32 * A_LD) = va1;
+    *reinterpret_cast<float4*>(a_st + 64 * A_LD) = va2;
+    *reinterpret_cast<float4*>(a_st + 96 * A_LD) = va3;
+    *reinterpret_cast<float4*>(b_st) = vb0;
+    if (NB > 1) *reinterpret_cast<float4*>(b_st + 1024) = vb1;
+    if (NB > 2) { *reinterpret_cast<float4*>(b_st + 2048) = vb2; *reinterpret_cast<float4*>(b_st + 3072) = vb3; }
+    __syncthreads();
+    mfma_tile<WM, WN, MI, NI>(a_ld, b_ld, acc);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int64_t n = n0 + (wn * NI + j) * 32 + l31;
+      if (n >= g.N) continue;
+      if (g.nsplit > 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < g.M) g.ws[((int64_t)split * g.M + m) * g.N + n] = acc[i][j][r];
+        }
+        continue;
+      }
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (g.emb) v += g.emb[(int64_t)g.bid[m] * g.lde + n];
+        if (g.res) v += g.res[m * g.ldr + n];
+        g.out[m * g.ldc + n] = v;
+      }
+    }
+  }
+}
+
+// aux[0, :] = 0; aux[1 + v, :] = mean over segment multi_seg[v] of x[col, :]
+__global__ void __launch_bounds__(256) multi_mean_kernel(const float* __restrict__ x, int64_t ldx, int cin,
+                                                         const int32_t* __restrict__ seg_ptr,
+                                                         const int32_t* __restrict__ col,
+                                                         const int32_t* __restrict__ multi_seg, int64_t V,
+                                                         float* __restrict__ aux, int64_t ldaux) {
+  const int c4n = cin >> 2;
+  const int64_t total = (V + 1) * c4n;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = t / c4n;
+    const int c = (int)(t - v * c4n) * 4;
+    float4 acc = f4zero();
+    if (v > 0) {
+      const int64_t s = multi_seg[v - 1];
+      const int32_t a = seg_ptr[s], e = seg_ptr[s + 1];
+      for (int32_t p = a; p < e; ++p) f4add(acc, *reinterpret_cast<const float4*>(x + (int64_t)col[p] * ldx + c));
+      const float inv = 1.f / (float)(e - a);
+      acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    }
+    *reinterpret_cast<float4*>(aux + v * ldaux + c) = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmArgs g) {
+  const int64_t total = g.M * g.N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = t / g.N, n = t - m * g.N;
+    float v = 0.f;
+    for (int s = 0; s < g.nsplit; ++s) v += g.ws[(int64_t)s * total + t];
+    if (g.bias) v += g.bias[n];
+    if (g.emb) v += g.emb[(int64_t)g.bid[m] * g.lde + n];
+    if (g.res) v += g.res[m * g.ldr + n];
+    int64_t om = m;
+    if (g.out_rows) { om = g.out_rows[m]; if (om < 0) continue; }
+    g.out[om * g.ldc + n] = v;
+  }
+}
+
+template <int MODE, int WM, int WN, int MI, int NI>
+static int launch_cfg(GemmArgs& g, hipStream_t st) {
+  constexpr int BN = WN * NI * 32;
+  constexpr size_t lds = (2 * BM * A_LD + 2 * 8 * BN * 4) * sizeof(float);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {     // 68 KB for BN = 128: above the 64 KB default cap
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, WM, WN, MI, NI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return OFX_ELAUNCH;
+    attr_set = true;
+  }
+  gemm_kernel<MODE, WM, WN, MI, NI><<<g.ntm * g.ntn * g.nsplit, 256, lds, st>>>(g);
+  return OFX_OK;
+}
+
+template <int WM, int WN, int MI, int NI>
+static int launch_fast_cfg(GemmArgs& g, hipStream_t st) {
+  constexpr int BN = WN * NI * 32;
+  constexpr size_t lds = (2 * BM * A_LD + 2 * 8 * BN * 4) * sizeof(float);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_gemm_fast_kernel<WM, WN, MI, NI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return OFX_ELAUNCH;
+    attr_set = true;
+  }
+  gather_gemm_fast_kernel<WM, WN, MI, NI><<<g.ntm * g.ntn * g.nsplit, 256, lds, st>>>(g);
+  return OFX_OK;
+}
+
+template <int MODE>
+static int launch_gemm(GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st) {
+  if (g.M <= 0 || g.N <= 0) return OFX_OK;
+  const int bn = g.N <= 32 ? 32 : (g.N <= 64 ? 64 : 128);
+  g.ntm = (int)ofx_cdiv(g.M, BM);
+  g.ntn = (int)ofx_cdiv(g.N, bn);
+  const int nkt = (int)(g.Kp / BK);
+  // split-K when the tile grid cannot fill 256 CUs (x2 blocks) and K is long enough to share
+  int nsplit = 1;
+  const int tiles = g.ntm * g.ntn;
+  if (ws && tiles < 256 && nkt >= 8) {
+    nsplit = (int)ofx_cdiv(512, tiles);
+    if (nsplit > nkt / 4) nsplit = nkt / 4;
+    if (nsplit > 64) nsplit = 64;
+    const size_t per = (size_t)g.M * g.N * sizeof(float);
+    if ((size_t)nsplit * per > ws_bytes) nsplit = (int)(ws_bytes / per);
+    if (nsplit < 2) nsplit = 1;
+  }
+  g.kt_per_split = (int)ofx_cdiv(nkt, nsplit);
+  nsplit = (int)ofx_cdiv(nkt, g.kt_per_split);
+  g.nsplit = nsplit;
+  g.ws = ws;
+  int rc;
+  const bool fast = MODE == MODE_GATHER && g.fast && g.nbr_ext && g.aux && !g.out_rows;
+  if (fast) {
+    if (bn == 32) rc = launch_fast_cfg<4, 1, 1, 1>(g, st);
+    else if (bn == 64) rc = launch_fast_cfg<2, 2, 2, 1>(g, st);
+    else rc = launch_fast_cfg<2, 2, 2, 2>(g, st);
+  } else if (bn == 32) rc = launch_cfg<MODE, 4, 1, 1, 1>(g, st);
+  else if (bn == 64) rc = launch_cfg<MODE, 2, 2, 2, 1>(g, st);
+  else rc = launch_cfg<MODE, 2, 2, 2, 2>(g, st);
+  if (rc) return rc;
+  if (nsplit > 1) splitk_reduce_kernel<<<ofx_grid(g.M * g.N, 256), 256, 0, st>>>(g);
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
@@ -319,9 +718,39 @@ extern "C" int ofx_pack_weights(const float* W, int64_t sk, int64_t sn, int64_t 
   return OFX_OK;
 }
 
+// nn.Conv3d weight [cout, cin, 3,3,3] -> packed k = tap*cin + c, tap = (kx*3+ky)*3+kz
+__global__ void pack_conv3d_kernel(const float* __restrict__ W, int cin, int64_t N, float* __restrict__ Wp, int64_t Kp) {
+  const int64_t total = (Kp / 4) * N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t kq = t / N, n = t - kq * N;
+    float v[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int64_t k = kq * 4 + kk;
+      float w = 0.f;
+      if (k < 27 * (int64_t)cin) {
+        const int64_t tap = k / cin, c = k - tap * cin;
+        w = W[(n * cin + c) * 27 + tap];
+      }
+      v[kk] = w;
+    }
+    *reinterpret_cast<float4*>(Wp + t * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+extern "C" int64_t ofx_conv3d_packed_k(int cin) { return pad32(27 * (int64_t)cin); }
+
+extern "C" int ofx_pack_conv3d(const float* W, int cin, int cout, float* Wp, void* stream) {
+  if (!W || !Wp || cin < 1 || cout < 1 || ((uintptr_t)Wp & 15)) return OFX_EINVAL;
+  const int64_t Kp = ofx_conv3d_packed_k(cin);
+  pack_conv3d_kernel<<<ofx_grid((Kp / 4) * cout, 256), 256, 0, ofx_stream(stream)>>>(W, cin, cout, Wp, Kp);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
 extern "C" int ofx_gemm_f32(const float* A, int64_t lda, const int32_t* a_rows, int64_t M, int64_t K, const float* Wp,
                             int64_t Kp, int64_t N, const float* bias, const float* res, int64_t ldr, float* out,
-                            int64_t ldc, const int32_t* out_rows, void* stream) {
+                            int64_t ldc, const int32_t* out_rows, void* ws, size_t ws_bytes, void* stream) {
   if (M < 0 || K < 1 || N < 1 || !Wp || !out || (M > 0 && !A) || Kp != pad32(K) || lda < K || ldc < N ||
       (res && ldr < N) || ((uintptr_t)Wp & 15))
     return OFX_EINVAL;
@@ -329,27 +758,70 @@ extern "C" int ofx_gemm_f32(const float* A, int64_t lda, const int32_t* a_rows, 
   g.A = A; g.lda = lda; g.a_rows = a_rows;
   g.M = M; g.K = K; g.Wp = Wp; g.Kp = Kp; g.N = N; g.bias = bias;
   g.res = res; g.ldr = ldr; g.out = out; g.ldc = ldc; g.out_rows = out_rows;
-  return launch_gemm<MODE_DENSE>(g, ofx_stream(stream));
+  return launch_gemm<MODE_DENSE>(g, (float*)ws, ws_bytes, ofx_stream(stream));
 }
 
-extern "C" int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes, const int32_t* seg_ptr,
-                                 const int32_t* col, const float* type_frac, int64_t ldt, int nt_pad, const float* Wp,
-                                 int64_t Kp, int cout, const float* bias, const float* emb, int64_t lde,
-                                 const int32_t* batch_id, const float* res, int64_t ldr, float* out, int64_t ldc,
-                                 void* stream) {
-  if (n_nodes < 0 || cin < 1 || cout < 1 || !x || !seg_ptr || !col || !Wp || !out || ldx < cin || ldc < cout ||
+static int gather_common(GemmArgs& g, const float* x, int64_t ldx, int cin, int ndir, int64_t n_rows,
+                         const int32_t* nbr, const int32_t* seg_ptr, const int32_t* col, const float* Wp, int64_t Kp,
+                         int cout, const float* bias, const float* emb, int64_t lde, const int32_t* batch_id,
+                         const float* res, int64_t ldr, float* out, int64_t ldc) {
+  if (n_rows < 0 || cin < 1 || cout < 1 || !x || !nbr || !Wp || !out || ldx < cin || ldc < cout ||
       (res && ldr < cout) || (emb && (!batch_id || lde < cout)) || ((uintptr_t)Wp & 15))
     return OFX_EINVAL;
-  const int64_t Kf = pad32(7 * (int64_t)cin);
-  if (nt_pad < 0 || (nt_pad & 31) || Kp != Kf + nt_pad) return OFX_EINVAL;
-  if (nt_pad > 0 && (!type_frac || ldt < nt_pad || (ldt & 3) || ((uintptr_t)type_frac & 15))) return OFX_EINVAL;
-  GemmArgs g = {};
-  g.x = x; g.ldx = ldx; g.cin = cin;
+  g.x = x; g.ldx = ldx; g.cin = cin; g.ndir = ndir;
   g.fast = (cin % 32 == 0) && ((ldx & 3) == 0) && (((uintptr_t)x & 15) == 0);
-  g.seg_ptr = seg_ptr; g.col = col; g.tf = type_frac; g.ldt = ldt; g.Kf = Kf;
-  g.M = n_nodes; g.K = Kp; g.Wp = Wp; g.Kp = Kp; g.N = cout; g.bias = bias;
+  g.nbr = nbr; g.seg_ptr = seg_ptr; g.col = col;
+  g.Kf = pad32((int64_t)ndir * cin);
+  g.M = n_rows; g.K = Kp; g.Wp = Wp; g.Kp = Kp; g.N = cout; g.bias = bias;
   g.emb = emb; g.lde = lde; g.bid = batch_id; g.res = res; g.ldr = ldr; g.out = out; g.ldc = ldc;
-  return launch_gemm<MODE_GATHER>(g, ofx_stream(stream));
+  return OFX_OK;
+}
+
+extern "C" int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes, const int32_t* nbr,
+                                 const int32_t* seg_ptr, const int32_t* col, const int32_t* nbr_ext,
+                                 const int32_t* multi_seg, int64_t n_multi, float* aux, const float* type_frac,
+                                 int64_t ldt, int nt_pad, const float* Wp, int64_t Kp, int cout, const float* bias,
+                                 const float* emb, int64_t lde, const int32_t* batch_id, const float* res, int64_t ldr,
+                                 float* out, int64_t ldc, void* ws, size_t ws_bytes, void* stream) {
+  GemmArgs g = {};
+  int rc = gather_common(g, x, ldx, cin, 7, n_nodes, nbr, seg_ptr, col, Wp, Kp, cout, bias, emb, lde, batch_id, res,
+                         ldr, out, ldc);
+  if (rc) return rc;
+  if (!seg_ptr || !col) return OFX_EINVAL;
+  if (nt_pad < 0 || (nt_pad & 31) || Kp != g.Kf + nt_pad) return OFX_EINVAL;
+  if (nt_pad > 0 && (!type_frac || ldt < nt_pad || (ldt & 3) || ((uintptr_t)type_frac & 15))) return OFX_EINVAL;
+  g.tf = type_frac; g.ldt = ldt;
+  hipStream_t st = ofx_stream(stream);
+  if (g.fast && nbr_ext && aux && n_nodes > 0 && (((uintptr_t)aux & 15) == 0)) {
+    if (n_multi < 0 || (n_multi > 0 && !multi_seg)) return OFX_EINVAL;
+    // pre-pass: zero row + mean rows of the (few) segments with several neighbours
+    multi_mean_kernel<<<ofx_grid((n_multi + 1) * (cin / 4), 256), 256, 0, st>>>(x, ldx, cin, seg_ptr, col, multi_seg,
+                                                                               n_multi, aux, ldx);
+    g.nbr_ext = nbr_ext; g.aux = aux; g.ldaux = ldx; g.n_src = n_nodes;
+    if (!g.tf) { g.tf = x; g.ldt = ldx; }       // never dereferenced past the gather tiles; keeps selects defined
+  }
+  return launch_gemm<MODE_GATHER>(g, (float*)ws, ws_bytes, st);
+}
+
+extern "C" int ofx_gridconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_in, int64_t n_out,
+                                const int32_t* nbr27, const int32_t* nbr27_ext, const float* zero_row,
+                                const float* Wp, int cout,
+                                const float* bias, const float* emb, int64_t lde, const int32_t* batch_id,
+                                const float* res, int64_t ldr, float* out, int64_t ldc, void* ws, size_t ws_bytes,
+                                void* stream) {
+  GemmArgs g = {};
+  const int64_t Kp = ofx_conv3d_packed_k(cin);
+  int rc = gather_common(g, x, ldx, cin, 27, n_out, nbr27 ? nbr27 : nbr27_ext, nullptr, nullptr, Wp, Kp, cout, bias,
+                         emb, lde, batch_id, res, ldr, out, ldc);
+  if (rc) return rc;
+  if (n_in < 1) return OFX_EINVAL;
+  if (g.fast && nbr27_ext && zero_row && (((uintptr_t)zero_row & 15) == 0)) {
+    g.nbr_ext = nbr27_ext; g.aux = zero_row; g.ldaux = ldx; g.n_src = n_in;   // padded taps name row n_in = zero row
+    g.tf = x; g.ldt = ldx;
+  } else if (!nbr27) {
+    return OFX_EINVAL;            // generic path needs the -1-padded table
+  }
+  return launch_gemm<MODE_GATHER>(g, (float*)ws, ws_bytes, ofx_stream(stream));
 }
 
 // ---------------------------------------------------------------------------------

@@ -335,3 +335,52 @@ extern "C" int ofx_graph_type_frac(const int32_t* seg_ptr, const int32_t* col, c
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
+
+// primary-neighbour table for the fused GraphConv: nbr[r*7+dir] = the single neighbour, -1 if the
+// segment is empty, -2 if it holds several neighbours (the kernel then walks the CSR segment).
+__global__ void graph_primary_kernel(const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ col, int64_t nseg,
+                                     int32_t* __restrict__ nbr) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t a = seg_ptr[s], e = seg_ptr[s + 1];
+    nbr[s] = e == a ? -1 : (e - a == 1 ? col[a] : -2);
+  }
+}
+extern "C" int ofx_graph_primary(const int32_t* seg_ptr, const int32_t* col, int64_t n_nodes, int32_t* nbr,
+                                 void* stream) {
+  if (!seg_ptr || !col || !nbr || n_nodes < 0) return OFX_EINVAL;
+  graph_primary_kernel<<<ofx_grid(n_nodes * 7, 256), 256, 0, ofx_stream(stream)>>>(seg_ptr, col, n_nodes * 7, nbr);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+// Extended table for the branch-free GraphConv kernel: every (row,dir) names a source row:
+//   single neighbour -> its id; none -> N (the zero row of the aux buffer);
+//   several -> N + 1 + v, where v = rank among multi-neighbour segments (multi_seg[v] = segment id).
+__global__ void graph_multi_flag_kernel(const int32_t* __restrict__ seg_ptr, int64_t nseg, int32_t* __restrict__ flag) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * blockDim.x)
+    flag[s] = (seg_ptr[s + 1] - seg_ptr[s]) > 1;
+}
+__global__ void graph_primary_ext_kernel(const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ col,
+                                         int64_t nseg, int64_t N, const int32_t* __restrict__ rank,
+                                         int32_t* __restrict__ nbr_ext, int32_t* __restrict__ multi_seg) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t a = seg_ptr[s], e = seg_ptr[s + 1];
+    if (e == a) nbr_ext[s] = (int32_t)N;
+    else if (e - a == 1) nbr_ext[s] = col[a];
+    else { nbr_ext[s] = (int32_t)(N + 1 + rank[s]); multi_seg[rank[s]] = (int32_t)s; }
+  }
+}
+extern "C" int ofx_graph_multi_flag(const int32_t* seg_ptr, int64_t n_nodes, int32_t* flag, void* stream) {
+  if (!seg_ptr || !flag || n_nodes < 0) return OFX_EINVAL;
+  graph_multi_flag_kernel<<<ofx_grid(n_nodes * 7, 256), 256, 0, ofx_stream(stream)>>>(seg_ptr, n_nodes * 7, flag);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+extern "C" int ofx_graph_primary_ext(const int32_t* seg_ptr, const int32_t* col, int64_t n_nodes, const int32_t* rank,
+                                     int32_t* nbr_ext, int32_t* multi_seg, void* stream) {
+  if (!seg_ptr || !col || !rank || !nbr_ext || n_nodes < 0) return OFX_EINVAL;
+  graph_primary_ext_kernel<<<ofx_grid(n_nodes * 7, 256), 256, 0, ofx_stream(stream)>>>(seg_ptr, col, n_nodes * 7,
+                                                                                      n_nodes, rank, nbr_ext, multi_seg);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}

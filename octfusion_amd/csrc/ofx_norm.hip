@@ -84,7 +84,7 @@ extern "C" int ofx_gn_stats(const float* x, int64_t ldx, int64_t n, int C, const
 }
 
 __global__ void gn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ count, int B, int C, int G,
-                                   float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+                                   float eps, float count_eps, float* __restrict__ mean, float* __restrict__ rstd) {
   const int cpg = C / G;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < B * G; t += gridDim.x * blockDim.x) {
     const int b = t / G, g = t - b * G;
@@ -94,7 +94,7 @@ __global__ void gn_finalize_kernel(const double* __restrict__ sums, const float*
       SS += sums[((int64_t)b * C + c) * 2 + 1];
     }
     const float cnt = count[b] * (float)cpg;            // modules.py:301-302 (fp32)
-    const float inv = 1.0f / (cnt + eps);
+    const float inv = 1.0f / (cnt + count_eps);         // reference adds eps to the COUNT (:302); nn.GroupNorm does not
     const double m = S * (double)inv;
     const double ssd = SS - 2.0 * m * S + (double)cnt * m * m;
     const double var = (ssd > 0 ? ssd : 0) * (double)inv;
@@ -107,10 +107,10 @@ __global__ void gn_finalize_kernel(const double* __restrict__ sums, const float*
 }
 
 extern "C" int ofx_gn_finalize(const double* sums, const float* count, int batch_size, int C, int groups, float eps,
-                               float* mean, float* rstd, void* stream) {
+                               float count_eps, float* mean, float* rstd, void* stream) {
   if (!sums || !count || !mean || !rstd || batch_size < 1 || C < 1 || groups < 1 || C % groups) return OFX_EINVAL;
   gn_finalize_kernel<<<ofx_grid((int64_t)batch_size * groups, 64), 64, 0, ofx_stream(stream)>>>(
-      sums, count, batch_size, C, groups, eps, mean, rstd);
+      sums, count, batch_size, C, groups, eps, count_eps, mean, rstd);
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }

@@ -276,55 +276,53 @@ __global__ void __launch_bounds__(256) o2v_kernel(float* __restrict__ data, int6
                                                   float* __restrict__ vox) {
   __shared__ float tile[64][65];
   const int S = 1 << d;
-  const int64_t per = (int64_t)S * S * S;
-  const int64_t r0 = (int64_t)blockIdx.x * 64;   // 64 consecutive rows of one batch element (per % 64 == 0 for d >= 2)
+  const int64_t per = (int64_t)S * S * S, rows = per * B;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
   const int c0 = blockIdx.y * 64;
-  const int64_t b = r0 / per;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  // voxel side: thread tx <-> row r0 + tx
+  const int64_t rv = r0 + tx;
+  const int64_t bv = rv < rows ? rv / per : 0;
+  int x, y, z, bb;
+  ofx_key2xyz(rv - bv * per, x, y, z, bb);
+  const int64_t voff = ((int64_t)x * S + y) * S + z;
   if (TO_VOX) {
     for (int rr = ty; rr < 64; rr += 4) {
       const int c = c0 + tx;
-      tile[rr][tx] = (c < C && r0 + rr < per * B) ? data[(r0 + rr) * ld + c] : 0.f;
+      tile[rr][tx] = (c < C && r0 + rr < rows) ? data[(r0 + rr) * ld + c] : 0.f;
     }
     __syncthreads();
-    // thread tx <-> local row (voxel) tx; iterate channels
-    int x, y, z, bb;
-    ofx_key2xyz((r0 + tx) - b * per, x, y, z, bb);
-    const int64_t voff = ((int64_t)x * S + y) * S + z;
     for (int cc = ty; cc < 64; cc += 4) {
       const int c = c0 + cc;
-      if (c < C && r0 + tx < per * B) vox[(b * C + c) * per + voff] = tile[tx][cc];
+      if (c < C && rv < rows) vox[(bv * C + c) * per + voff] = tile[tx][cc];
     }
   } else {
-    int x, y, z, bb;
-    ofx_key2xyz((r0 + tx) - b * per, x, y, z, bb);
-    const int64_t voff = ((int64_t)x * S + y) * S + z;
     for (int cc = ty; cc < 64; cc += 4) {
       const int c = c0 + cc;
-      tile[tx][cc] = (c < C && r0 + tx < per * B) ? vox[(b * C + c) * per + voff] : 0.f;
+      tile[tx][cc] = (c < C && rv < rows) ? vox[(bv * C + c) * per + voff] : 0.f;
     }
     __syncthreads();
     for (int rr = ty; rr < 64; rr += 4) {
       const int c = c0 + tx;
-      if (c < C && r0 + rr < per * B) data[(r0 + rr) * ld + c] = tile[rr][tx];
+      if (c < C && r0 + rr < rows) data[(r0 + rr) * ld + c] = tile[rr][tx];
     }
   }
 }
 
 extern "C" int ofx_octree2voxel_cf(const float* data, int64_t ld, int C, int batch_size, int depth, float* vox,
                                    void* stream) {
-  if (!data || !vox || C < 1 || batch_size < 1 || depth < 2 || depth > 8 || ld < C) return OFX_EINVAL;
+  if (!data || !vox || C < 1 || batch_size < 1 || depth < 0 || depth > 8 || ld < C) return OFX_EINVAL;
   const int64_t rows = (1ll << (3 * depth)) * batch_size;
-  dim3 grid((unsigned)(rows / 64), (unsigned)ofx_cdiv(C, 64));
+  dim3 grid((unsigned)ofx_cdiv(rows, 64), (unsigned)ofx_cdiv(C, 64));
   o2v_kernel<true><<<grid, 256, 0, ofx_stream(stream)>>>(const_cast<float*>(data), ld, C, batch_size, depth, vox);
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
 extern "C" int ofx_voxel2octree_cf(const float* vox, int C, int batch_size, int depth, float* data, int64_t ld,
                                    void* stream) {
-  if (!data || !vox || C < 1 || batch_size < 1 || depth < 2 || depth > 8 || ld < C) return OFX_EINVAL;
+  if (!data || !vox || C < 1 || batch_size < 1 || depth < 0 || depth > 8 || ld < C) return OFX_EINVAL;
   const int64_t rows = (1ll << (3 * depth)) * batch_size;
-  dim3 grid((unsigned)(rows / 64), (unsigned)ofx_cdiv(C, 64));
+  dim3 grid((unsigned)ofx_cdiv(rows, 64), (unsigned)ofx_cdiv(C, 64));
   o2v_kernel<false><<<grid, 256, 0, ofx_stream(stream)>>>(data, ld, C, batch_size, depth, const_cast<float*>(vox));
   OFX_LAUNCH_CHECK();
   return OFX_OK;

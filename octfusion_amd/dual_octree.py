@@ -77,6 +77,8 @@ class DualOctree:
 
         self.graph = [dict() for _ in range(depth + 1)]
         self._csr = {}
+        self._nbr = {}
+        self._ext = {}
         self._bid32 = {}
         self._count = {}
         self._tf = {}
@@ -110,6 +112,18 @@ class DualOctree:
         nmask = torch.empty(nm_len, dtype=torch.uint8, device=dev)
         call('ofx_graph_nodes', tree, d, ptr(bid), ptr(ntype), ptr(keyd), ptr(nmask), stream())
         self._csr[d] = (seg_ptr, col, N, E)
+        nbr = torch.empty(N * 7, dtype=torch.int32, device=dev)
+        call('ofx_graph_primary', ptr(seg_ptr), ptr(col), N, ptr(nbr), stream())
+        self._nbr[d] = nbr
+        flag = torch.empty(N * 7, dtype=torch.int32, device=dev)
+        call('ofx_graph_multi_flag', ptr(seg_ptr), N, ptr(flag), stream())
+        rank = torch.empty(N * 7 + 1, dtype=torch.int32, device=dev)
+        call('ofx_scan_i32', ptr(flag), ptr(rank), N * 7, ptr(ws), stream())
+        V = int(rank[-1].item())
+        nbr_ext = torch.empty(N * 7, dtype=torch.int32, device=dev)
+        multi_seg = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
+        call('ofx_graph_primary_ext', ptr(seg_ptr), ptr(col), N, ptr(rank), ptr(nbr_ext), ptr(multi_seg), stream())
+        self._ext[d] = (nbr_ext, multi_seg, V)
         self._bid32[d] = bid
         self._ntype8[d] = ntype
         self.batch_id_dict[d] = bid.to(torch.int64)
@@ -146,6 +160,14 @@ class DualOctree:
     def csr(self, d):
         """(seg_ptr int32 [N*7+1], col int32 [E], N, E)."""
         return self._csr[d]
+
+    def nbr(self, d):
+        """int32 [N*7]: the single neighbour of segment (row, dir), -1 none, -2 several (see csr)."""
+        return self._nbr[d]
+
+    def ext(self, d):
+        """(nbr_ext int32 [N*7], multi_seg int32 [V], V): the branch-free gather table (ofx.h)."""
+        return self._ext[d]
 
     def batch_id32(self, d):
         return self._bid32[d]

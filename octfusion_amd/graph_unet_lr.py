@@ -2,28 +2,93 @@
 
 Mirror of reference models/networks/diffusion_networks/graph_unet_lr.py
 (``UNet3DModel``: ctor :65-173, forward :184-230, forward_as_middle :175-182)
-with the reference's dense blocks (modules.py:26-95, 474-563): same constructor
-keywords, signatures and state_dict keys (time_pos_emb.weights, time_emb.*,
-input_emb.*, downs/ups.*, mid_*, end.*, out.*).
+and its dense blocks (modules.py:26-95, 474-563): same constructor keywords,
+signatures and state_dict keys (time_pos_emb.weights, time_emb.*, input_emb.*,
+downs/ups.*, mid_*, end.*, out.* with nn.Conv3d / nn.GroupNorm / nn.Conv1d
+parameter shapes).
 
-This part of the step is tiny and dense (B x 16^3 voxels; <5 % of the step's
-FLOPs): 3x3x3 convolutions and GroupNorm use the
-ROCm libraries through ATen (MIOpen / rocBLAS); the octree<->voxel permutations
-at the boundary are libofx kernels.  No CPU path: forward_as_middle goes through
-libofx and raises without it.
+MI355X design: the whole net runs in the octree's node-row layout.  A full
+octree layer of depth d (16^3, 8^3, 4^3 ...) is rows ``b*8^d + morton(x,y,z)``
+with channels contiguous, exactly what the sparse "hr" net hands over, so the
+reference's octree2voxel / permute / gather-back (graph_unet_lr.py:176-181)
+disappear.  Every 3x3x3 convolution -- stride 1, the stride-2 ConvDownsample
+and the nearest-upsample+conv ConvUpsample (no upsampled tensor is ever
+written) -- is the fused gather-GEMM of libofx with a 27-tap neighbour table
+(built once per (batch, depth), independent of the octree); the time-embedding
+add and the residual are fused into the conv epilogues; GroupNorm+SiLU is the
+two-kernel libofx norm; attention is a libofx kernel.  No MIOpen / ATen compute.
 """
 import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
+from .modules import _Linear
+
+
+class _GridCache:
+    """Per (batch, device): row-layout tables of the dense layers (octree independent)."""
+
+    _cache = {}
+
+    @classmethod
+    def get(cls, batch_size, device):
+        key = (batch_size, device.type, device.index)
+        c = cls._cache.get(key)
+        if c is None:
+            c = cls(batch_size, device)
+            cls._cache[key] = c
+        return c
+
+    def __init__(self, batch_size, device):
+        self.B = batch_size
+        self.device = device
+        self._tab = {}
+        self._bid = {}
+        self._cnt = {}
+
+    def table(self, mode, depth_out, fast):
+        """27-tap neighbour table; out-of-grid taps = n_in (zero row; branch-free kernel) or -1 (generic)."""
+        k = (mode, depth_out, fast)
+        if k not in self._tab:
+            d_in = depth_out + (0, 1, -1)[mode]
+            pad = self.B * 8 ** d_in if fast else -1
+            self._tab[k] = ops.grid_conv_table(mode, depth_out, self.B, self.device, pad)
+        return self._tab[k]
+
+    def batch_id(self, depth):
+        if depth not in self._bid:
+            per = 8 ** depth
+            self._bid[depth] = (torch.arange(self.B * per, device=self.device) // per).to(torch.int32)
+            self._cnt[depth] = torch.full((self.B,), float(per), dtype=torch.float32, device=self.device)
+        return self._bid[depth]
+
+    def count(self, depth):
+        self.batch_id(depth)
+        return self._cnt[depth]
+
+
+class GridState:
+    """What a dense block needs to know about its input: batch, depth, cached tables."""
+
+    def __init__(self, batch_size, depth, device):
+        self.B, self.depth = batch_size, depth
+        self.cache = _GridCache.get(batch_size, device)
+
+    def at(self, depth):
+        g = GridState.__new__(GridState)
+        g.B, g.depth, g.cache = self.B, depth, self.cache
+        return g
 
 
 class GroupNorm32(nn.GroupNorm):
-    def forward(self, x):
-        return super().forward(x.float()).type(x.dtype)
+    """reference modules.py:26-28 (parameters ``weight`` / ``bias`` [C]); runs on libofx in row layout."""
+
+    @torch.no_grad()
+    def forward(self, x, gs, act=None, out=None):
+        return ops.group_norm(x, gs.cache.batch_id(gs.depth), gs.cache.count(gs.depth), gs.B, self.weight,
+                              self.bias, self.num_groups, self.eps, act, out, count_eps=0.0)
 
 
 def convnormalization(channels):
@@ -35,24 +100,74 @@ class our_Identity(nn.Module):
         return x
 
 
+class GridConv3d(nn.Module):
+    """nn.Conv3d(cin, cout, 3, padding=1[, stride]) parameters; 27-tap gather-GEMM compute.
+
+    mode 0: stride 1; mode 1: stride 2 (depth d -> d-1); mode 2: nearest x2 upsample then conv
+    (depth d -> d+1)."""
+
+    def __init__(self, cin, cout, mode=0):
+        super().__init__()
+        self.in_channels, self.out_channels, self.mode = cin, cout, mode
+        self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3, 3))
+        self.bias = nn.Parameter(torch.empty(cout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(cin * 27)
+        nn.init.uniform_(self.bias, -bound, bound)
+        self._pw = ops.PackedConv3d()
+
+    def out_depth(self, depth):
+        return depth + (0, -1, 1)[self.mode]
+
+    @torch.no_grad()
+    def forward(self, x, gs, emb=None, res=None):
+        d_out = self.out_depth(gs.depth)
+        n_out = gs.B * 8 ** d_out
+        bid = gs.cache.batch_id(d_out) if emb is not None else None
+        mode = self.mode
+        return ops.gridconv(x, lambda fast: gs.cache.table(mode, d_out, fast), n_out, self._pw.get(self.weight),
+                            self.bias, emb, bid, res)
+
+
+class _PointConv(nn.Module):
+    """1x1 conv with nn.Conv{1,3}d-shaped ``weight`` ([cout, cin, 1(,1,1)]) on the MFMA GEMM."""
+
+    def __init__(self, cin, cout, kdims):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, *([1] * kdims)))
+        self.bias = nn.Parameter(torch.empty(cout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        nn.init.uniform_(self.bias, -1 / math.sqrt(cin), 1 / math.sqrt(cin))
+        self._pw = ops.PackedWeight()
+
+    @torch.no_grad()
+    def forward(self, x, res=None):
+        w = self.weight.view(self.weight.shape[0], self.weight.shape[1])
+        return ops.gemm(x, self._pw.get(w, 'nk'), self.bias, res)
+
+
 class ConvUpsample(nn.Module):
+    """reference modules.py:63-78 (``conv.weight``)."""
+
     def __init__(self, channels, use_conv=True, dims=3):
         super().__init__()
         self.channels = channels
-        self.conv = nn.Conv3d(channels, channels, 3, padding=1)
+        self.conv = GridConv3d(channels, channels, mode=2)
 
-    def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2, mode='nearest'))
+    def forward(self, x, gs):
+        return self.conv(x, gs), gs.at(gs.depth + 1)
 
 
 class ConvDownsample(nn.Module):
+    """reference modules.py:81-95 (``op.weight``)."""
+
     def __init__(self, channels, use_conv=True, dims=3):
         super().__init__()
         self.channels = channels
-        self.op = nn.Conv3d(channels, channels, 3, stride=2, padding=1)
+        self.op = GridConv3d(channels, channels, mode=1)
 
-    def forward(self, x):
-        return self.op(x)
+    def forward(self, x, gs):
+        return self.op(x, gs), gs.at(gs.depth - 1)
 
 
 class ResnetBlock(nn.Module):
@@ -61,32 +176,27 @@ class ResnetBlock(nn.Module):
     def __init__(self, world_dims, dim_in, dim_out, emb_dim, dropout=0.1, use_text_condition=False):
         super().__init__()
         assert world_dims == 3 and not use_text_condition
-        self.time_mlp = nn.Sequential(nn.SiLU(), nn.Linear(emb_dim, dim_out))
-        self.block1 = nn.Sequential(convnormalization(dim_in), nn.SiLU(),
-                                    nn.Conv3d(dim_in, dim_out, 3, padding=1))
-        conv2 = nn.Conv3d(dim_out, dim_out, 3, padding=1)
+        self.time_mlp = nn.Sequential(nn.SiLU(), _Linear(emb_dim, dim_out))
+        self.block1 = nn.Sequential(convnormalization(dim_in), nn.SiLU(), GridConv3d(dim_in, dim_out))
+        conv2 = GridConv3d(dim_out, dim_out)
         for p in conv2.parameters():
             p.detach().zero_()
         self.block2 = nn.Sequential(convnormalization(dim_out), nn.SiLU(), nn.Dropout(dropout), conv2)
-        self.res_conv = nn.Conv3d(dim_in, dim_out, 1) if dim_in != dim_out else nn.Identity()
+        self.res_conv = _PointConv(dim_in, dim_out, 3) if dim_in != dim_out else nn.Identity()
 
-    def forward(self, x, time_emb, text_condition=None):
-        h = self.block1(x)
-        h = h + self.time_mlp(time_emb)[:, :, None, None, None]
-        h = self.block2(h)
-        return h + self.res_conv(x)
+    @torch.no_grad()
+    def forward(self, x, emb_act, gs):
+        """emb_act = SiLU(time embedding) [B, emb_dim] (shared by all blocks of a step)."""
+        h = self.block1[0](x, gs, act='silu')
+        t = self.time_mlp[1](emb_act)                       # [B, dim_out]
+        h = self.block1[2](h, gs, emb=t)                    # conv + bias + t[batch] fused
+        h = self.block2[0](h, gs, act='silu', out=h)
+        skip = x if isinstance(self.res_conv, nn.Identity) else self.res_conv(x)
+        return self.block2[3](h, gs, res=skip)
 
 
 class QKVAttention(nn.Module):
-    """reference modules.py:538-547."""
-
-    def forward(self, qkv):
-        ch = qkv.shape[1] // 3
-        q, k, v = torch.split(qkv, ch, dim=1)
-        scale = 1 / math.sqrt(math.sqrt(ch))
-        weight = torch.einsum('bct,bcs->bts', q * scale, k * scale)
-        weight = torch.softmax(weight.float(), dim=-1).type(weight.dtype)
-        return torch.einsum('bts,bcs->bct', weight, v)
+    """reference modules.py:538-547 -- computed by ofx_attention."""
 
 
 class AttentionBlock(nn.Module):
@@ -97,23 +207,28 @@ class AttentionBlock(nn.Module):
         self.channels = channels
         self.num_heads = num_heads
         self.norm = convnormalization(channels)
-        self.qkv = nn.Conv1d(channels, channels * 3, 1)
+        self.qkv = _PointConv(channels, channels * 3, 1)
         self.attention = QKVAttention()
-        self.proj_out = nn.Conv1d(channels, channels, 1)
+        self.proj_out = _PointConv(channels, channels, 1)
         for p in self.proj_out.parameters():
             p.detach().zero_()
 
-    def forward(self, x):
-        b, c, *spatial = x.shape
-        x = x.reshape(b, c, -1)
-        qkv = self.qkv(self.norm(x))
-        qkv = qkv.reshape(b * self.num_heads, -1, qkv.shape[2])
-        h = self.attention(qkv).reshape(b, -1, qkv.shape[2])
-        return (x + self.proj_out(h)).reshape(b, c, *spatial)
+    @torch.no_grad()
+    def forward(self, x, gs):
+        qkv = self.qkv(self.norm(x, gs))
+        h = ops.attention(qkv, gs.B, 8 ** gs.depth, self.num_heads)
+        return self.proj_out(h, res=x)
+
+
+class _AttnSeq(nn.Sequential):
+    """Sequential(GroupNorm32, SiLU, AttentionBlock) of graph_unet_lr.py:128-132 (keys 0.*, 2.*)."""
+
+    def forward(self, x, gs):
+        return self[2](self[0](x, gs, act='silu'), gs)
 
 
 class LearnedSinusoidalPosEmb(nn.Module):
-    """reference modules.py:550-563."""
+    """reference modules.py:550-563 ([B] -> [B, dim+1]; a few hundred floats of host-side glue)."""
 
     def __init__(self, dim):
         super().__init__()
@@ -146,14 +261,14 @@ class UNet3DModel(nn.Module):
         in_out = list(zip(chans[:-1], chans[1:]))
         ted = mc * 4
         self.time_pos_emb = LearnedSinusoidalPosEmb(mc)
-        self.time_emb = nn.Sequential(nn.Linear(mc + 1, ted), nn.SiLU(), nn.Linear(ted, ted))
+        self.time_emb = nn.Sequential(_Linear(mc + 1, ted), nn.SiLU(), _Linear(ted, ted))
         if num_classes is not None:
             self.label_emb = nn.Embedding(num_classes, ted)
-        self.input_emb = nn.Conv3d(2 * self.in_channels, mc, 3, padding=1)
+        self.input_emb = GridConv3d(2 * self.in_channels, mc)
 
         def attn(c, ds):
             if ds in attention_resolutions:
-                return nn.Sequential(convnormalization(c), nn.SiLU(), AttentionBlock(c, num_heads=num_heads))
+                return _AttnSeq(convnormalization(c), nn.SiLU(), AttentionBlock(c, num_heads=num_heads))
             return our_Identity()
 
         self.downs = nn.ModuleList()
@@ -178,34 +293,62 @@ class UNet3DModel(nn.Module):
                 ConvUpsample(ci, dims=dims)]))
             ds //= 2
         self.end = nn.Sequential(convnormalization(mc), nn.SiLU())
-        self.out = nn.Conv3d(mc, self.out_channels, 3, padding=1)
+        self.out = GridConv3d(mc, self.out_channels)
+
+    # ---- row-layout core ------------------------------------------------
+    @torch.no_grad()
+    def _embed(self, timesteps, label, batch_size):
+        emb = self.time_emb[0](self.time_pos_emb(timesteps.float()).contiguous())
+        emb = self.time_emb[2](ops.act(emb, 'silu'))
+        if self.num_classes is not None:
+            assert label.shape == (batch_size,)
+            emb = emb + self.label_emb(label)
+        return ops.act(emb, 'silu')
 
     @torch.no_grad()
+    def forward_rows(self, x, batch_size, timesteps, label=None, as_middle=False):
+        """x [B*8^full_depth, C] in node-row layout; returns rows at full_depth."""
+        gs = GridState(batch_size, self.full_depth, x.device)
+        if not as_middle:
+            x = self.input_emb(x, gs)
+        emb_act = self._embed(timesteps, label, batch_size)
+
+        def run_attn(m, x, gs):
+            return x if isinstance(m, our_Identity) else m(x, gs)
+
+        hs = []
+        for resnet, self_attn, downsample in self.downs:
+            x = run_attn(self_attn, resnet(x, emb_act, gs), gs)
+            hs.append(x)
+            if not isinstance(downsample, our_Identity):
+                x, gs = downsample(x, gs)
+        x = self.mid_block1(x, emb_act, gs)
+        x = run_attn(self.mid_self_attn, x, gs)
+        x = self.mid_block2(x, emb_act, gs)
+        for resnet, self_attn, upsample in self.ups:
+            x = torch.cat((x, hs.pop()), dim=1)
+            x = run_attn(self_attn, resnet(x, emb_act, gs), gs)
+            x, gs = upsample(x, gs)
+        x = self.end[0](x, gs, act='silu')
+        return x if as_middle else self.out(x, gs)
+
+    # ---- reference signatures ---------------------------------------------
+    @torch.no_grad()
     def forward_as_middle(self, h, doctree, timesteps, label, context):
-        vox = ops.octree2voxel_cf(h, doctree.batch_size, self.full_depth)       # [B, C, S, S, S]
-        vox = self.forward(x=vox, timesteps=timesteps, label=label, context=context, as_middle=True)
-        return ops.voxel2octree_cf(vox, self.full_depth)
+        # rows of the full layer ARE the dense grid: no octree2voxel / gather-back needed
+        return self.forward_rows(h, doctree.batch_size, timesteps, label, as_middle=True)
 
     @torch.no_grad()
     def forward(self, x=None, timesteps=None, x_self_cond=None, label=None, context=None, as_middle=False,
                 **kwargs):
+        """Dense-tensor interface of the reference: x [B, C, S, S, S] -> [B, C', S, S, S]."""
         assert (label is not None) == (self.num_classes is not None), \
             'must specify label if and only if the model is class-conditional'
+        B = x.shape[0]
         if not as_middle:
             if x_self_cond is None:
                 x_self_cond = torch.zeros_like(x)
-            x = self.input_emb(torch.cat((x, x_self_cond), dim=1))
-        emb = self.time_emb(self.time_pos_emb(timesteps))
-        if self.num_classes is not None:
-            assert label.shape == (x.shape[0],)
-            emb = emb + self.label_emb(label)
-        hs = []
-        for resnet, self_attn, downsample in self.downs:
-            x = self_attn(resnet(x, emb))
-            hs.append(x)
-            x = downsample(x)
-        x = self.mid_block2(self.mid_self_attn(self.mid_block1(x, emb)), emb)
-        for resnet, self_attn, upsample in self.ups:
-            x = upsample(self_attn(resnet(torch.cat((x, hs.pop()), dim=1), emb)))
-        x = self.end(x)
-        return x if as_middle else self.out(x)
+            x = torch.cat((x, x_self_cond), dim=1)
+        rows = ops.voxel2octree_cf(x.float(), self.full_depth)
+        y = self.forward_rows(rows, B, timesteps, label, as_middle)
+        return ops.octree2voxel_cf(y, B, self.full_depth)

@@ -66,9 +66,9 @@ class GraphConv(nn.Module):
         seg_ptr, col, N, E = doctree.csr(d)
         assert x.shape[0] == N, 'x has %d rows, graph depth %d has %d nodes' % (x.shape[0], d, N)
         tf = doctree.type_frac(d, nt) if nt else None
-        return ops.graphconv(x, seg_ptr, col, pw, self.in_channels, tf,
+        return ops.graphconv(x, doctree.nbr(d), seg_ptr, col, pw, self.in_channels, tf,
                              self.bias if self.use_bias else None, emb,
-                             doctree.batch_id32(d) if emb is not None else None, res, out)
+                             doctree.batch_id32(d) if emb is not None else None, res, out, ext=doctree.ext(d))
 
     def extra_repr(self):
         return 'channel_in={}, channel_out={}, n_edge_type={}, avg_degree={}, n_node_type={}'.format(

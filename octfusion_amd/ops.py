@@ -39,6 +39,19 @@ def _row_major(t):
     return t, ld
 
 
+_WS = {}
+
+
+def workspace(device, nbytes=64 << 20):
+    """Per-device split-K scratch (partial tiles); reused by every launch on the stream."""
+    key = (device.type, device.index)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WS[key] = t
+    return t
+
+
 def scan_i32(x):
     """Exclusive scan; returns int32 tensor of n+1 entries (last = total)."""
     _chk(x, torch.int32)
@@ -102,13 +115,25 @@ def gemm(a, pw, bias=None, res=None, out=None, a_rows=None, out_rows=None, m=Non
     _chk(bias)
     _chk(a_rows, torch.int32)
     _chk(out_rows, torch.int32)
+    ws = workspace(a.device)
     call('ofx_gemm_f32', ptr(a), lda, ptr(a_rows), M, pw.K, ptr(pw.t), pw.Kp, pw.N, ptr(bias),
-         ptr(res), ldr, ptr(out), ldc, ptr(out_rows), stream())
+         ptr(res), ldr, ptr(out), ldc, ptr(out_rows), ptr(ws), ws.numel(), stream())
     return out
 
 
-def graphconv(x, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None, batch_id=None,
-              res=None, out=None):
+_ZEROS = {}
+
+
+def zero_row(device, n=4096):
+    key = (device.type, device.index)
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return _ZEROS[key]
+
+
+def graphconv(x, nbr, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None, batch_id=None,
+              res=None, out=None, ext=None):
+    """ext = (nbr_ext, multi_seg, n_multi) enables the branch-free fast path (cin % 32 == 0)."""
     """Fused dual-octree graph convolution (gather -> segment mean -> MFMA contraction)."""
     x, ldx = _row_major(x)
     N = x.shape[0]
@@ -135,9 +160,16 @@ def graphconv(x, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None, bat
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    call('ofx_graphconv_fwd', ptr(x), ldx, cin, N, ptr(seg_ptr), ptr(col), ptr(type_frac), ldt, nt_pad,
+    ws = workspace(x.device)
+    nbr_ext = multi_seg = aux = None
+    n_multi = 0
+    if ext is not None and cin % 32 == 0:
+        nbr_ext, multi_seg, n_multi = ext
+        aux = torch.empty((n_multi + 1) * ldx, dtype=torch.float32, device=x.device)
+    call('ofx_graphconv_fwd', ptr(x), ldx, cin, N, ptr(nbr), ptr(seg_ptr), ptr(col), ptr(nbr_ext), ptr(multi_seg),
+         n_multi, ptr(aux), ptr(type_frac), ldt, nt_pad,
          ptr(pw.t), pw.Kp, pw.N, ptr(bias), ptr(emb), lde, ptr(batch_id) if emb is not None else None,
-         ptr(res), ldr, ptr(out), ldc, stream())
+         ptr(res), ldr, ptr(out), ldc, ptr(ws), ws.numel(), stream())
     if prof is not None:
         e1.record()
         E = col.numel()
@@ -146,6 +178,73 @@ def graphconv(x, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None, bat
         # fused-op algorithmic bytes: one feature row per edge + output + weights + 8 B/edge
         nbytes = 4.0 * (E * cin + N * pw.N + k_logical * pw.N) + 8.0 * E
         prof.append((e0, e1, flops, nbytes))
+    return out
+
+
+class PackedConv3d:
+    """nn.Conv3d weight [cout, cin, 3, 3, 3] packed for the 27-tap gather-GEMM."""
+
+    def __init__(self):
+        self.t = None
+        self.key = None
+        self.cin = self.N = 0
+
+    def get(self, w):
+        key = (w.data_ptr(), w._version, tuple(w.shape))
+        if key == self.key:
+            return self
+        _chk(w)
+        cout, cin = w.shape[:2]
+        assert tuple(w.shape[2:]) == (3, 3, 3)
+        w = w.detach().contiguous()
+        Kp = _lib.lib().ofx_conv3d_packed_k(cin)
+        out = torch.empty((Kp // 4) * cout * 4, dtype=torch.float32, device=w.device)
+        call('ofx_pack_conv3d', ptr(w), cin, cout, ptr(out), stream())
+        self.t, self.key, self.cin, self.N = out, key, cin, cout
+        return self
+
+
+def gridconv(x, tables, n_out, pw, bias=None, emb=None, batch_id=None, res=None, out=None):
+    """3x3x3 convolution on a dense octree layer in node-row layout (27-tap gather-GEMM).
+    tables(fast) -> the neighbour table padded with n_in (fast) or -1 (generic)."""
+    x, ldx = _row_major(x)
+    if x.shape[1] != pw.cin:
+        raise ValueError('cin mismatch')
+    if out is None:
+        out = torch.empty(n_out, pw.N, dtype=torch.float32, device=x.device)
+    out2, ldc = _row_major(out)
+    assert out2 is out
+    lde = ldr = 0
+    if emb is not None:
+        emb, lde = _row_major(emb)
+        _chk(batch_id, torch.int32)
+    if res is not None:
+        res, ldr = _row_major(res)
+    _chk(bias)
+    ws = workspace(x.device)
+    fast = pw.cin % 32 == 0 and ldx % 4 == 0
+    call('ofx_gridconv_fwd', ptr(x), ldx, pw.cin, x.shape[0], n_out, None if fast else ptr(tables(False)),
+         ptr(tables(True)) if fast else None, ptr(zero_row(x.device)), ptr(pw.t), pw.N, ptr(bias), ptr(emb), lde,
+         ptr(batch_id) if emb is not None else None, ptr(res), ldr, ptr(out), ldc, ptr(ws), ws.numel(), stream())
+    return out
+
+
+def grid_conv_table(mode, depth_out, batch_size, device, pad=-1):
+    n = (8 ** depth_out) * batch_size
+    t = torch.empty(n, 27, dtype=torch.int32, device=device)
+    call('ofx_grid_conv_table', mode, depth_out, batch_size, pad, ptr(t), stream())
+    return t
+
+
+def attention(qkv, batch_size, T, heads, out=None):
+    qkv, ldq = _row_major(qkv)
+    C = qkv.shape[1] // 3
+    ch = C // heads
+    if out is None:
+        out = torch.empty(qkv.shape[0], C, dtype=torch.float32, device=qkv.device)
+    out2, ldo = _row_major(out)
+    assert out2 is out
+    call('ofx_attention', ptr(qkv), ldq, batch_size, T, heads, ch, ptr(out), ldo, stream())
     return out
 
 
@@ -158,8 +257,11 @@ def gather_mean(x, seg_ptr, col):
     return out
 
 
-def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, act=None, out=None):
-    """DualOctreeGroupNorm (+ optional fused activation)."""
+def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, act=None, out=None,
+               count_eps=None):
+    """DualOctreeGroupNorm (+ optional fused activation).  count_eps=0 gives torch.nn.GroupNorm."""
+    if count_eps is None:
+        count_eps = eps
     x, ldx = _row_major(x)
     n, C = x.shape
     dev = x.device
@@ -167,7 +269,8 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
     mean = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
     rstd = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
     call('ofx_gn_stats', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
-    call('ofx_gn_finalize', ptr(sums), ptr(count), batch_size, C, groups, eps, ptr(mean), ptr(rstd), stream())
+    call('ofx_gn_finalize', ptr(sums), ptr(count), batch_size, C, groups, eps, count_eps, ptr(mean), ptr(rstd),
+         stream())
     if out is None:
         out = torch.empty(n, C, dtype=torch.float32, device=dev)
     out2, ldo = _row_major(out)

@@ -248,17 +248,57 @@ def test_graphconv_wide_vs_oracle():
         close(m(x.to(dev()), doc, d, emb=emb.to(dev()), res=res.to(dev())), ref2)
 
 
+def to_rows(vox, depth):
+    from octfusion_amd import ops
+    return ops.voxel2octree_cf(vox.to(dev()).contiguous(), depth)
+
+
+def to_vox(rows, B, depth):
+    from octfusion_amd import ops
+    return ops.octree2voxel_cf(rows, B, depth)
+
+
+def test_gridconv_vs_torch():
+    """27-tap gather-GEMM conv (stride 1 / stride 2 / upsample+conv), fast + slow + split-K paths."""
+    import torch.nn.functional as F
+    from octfusion_amd import graph_unet_lr as LR
+    for B, d, cin, cout, mode in [(2, 3, 64, 48, 0), (2, 3, 16, 64, 0), (1, 4, 32, 8, 0), (2, 3, 64, 64, 1),
+                                  (2, 2, 96, 160, 2), (1, 2, 256, 128, 0), (3, 1, 64, 32, 0)]:
+        S = 1 << d
+        m = LR.GridConv3d(cin, cout, mode)
+        keys = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        sd = C.fill_state_dict(keys)
+        m.load_state_dict(sd)
+        m = m.to(dev())
+        x = C.rand_input('gridconv%d%d' % (cin, mode), B, cin, S, S, S)
+        if mode == 0:
+            ref = F.conv3d(x, sd['weight'], sd['bias'], padding=1)
+        elif mode == 1:
+            ref = F.conv3d(x, sd['weight'], sd['bias'], stride=2, padding=1)
+        else:
+            ref = F.conv3d(F.interpolate(x, scale_factor=2, mode='nearest'), sd['weight'], sd['bias'], padding=1)
+        gs = LR.GridState(B, d, dev())
+        y = m(to_rows(x, d), gs)
+        close(to_vox(y, B, m.out_depth(d)), ref)
+
+
 def test_dense_and_unet(golden):
-    from octfusion_amd import graph_unet_lr as LR, graph_unet_union as U
+    from octfusion_amd import graph_unet_lr as LR, graph_unet_union as U, ops
     G = golden('g_dense')
     r = G['attn']
-    close(load(LR.AttentionBlock(32, num_heads=4), r['keys'])(r['x'].to(dev())), r['out'])
+    m = load(LR.AttentionBlock(32, num_heads=4), r['keys'])
+    close(to_vox(m(to_rows(r['x'], 2), LR.GridState(2, 2, dev())), 2, 2), r['out'])
+    r = G['attn512']
+    m = load(LR.AttentionBlock(128, num_heads=4), r['keys'])
+    close(to_vox(m(to_rows(r['x'], 3), LR.GridState(1, 3, dev())), 1, 3), r['out'])
     r = G['resnet']
-    close(load(LR.ResnetBlock(3, 8, 12, emb_dim=16, dropout=0.0), r['keys'])(r['x'].to(dev()), r['emb'].to(dev())),
-          r['out'])
+    m = load(LR.ResnetBlock(3, 8, 12, emb_dim=16, dropout=0.0), r['keys'])
+    y = m(to_rows(r['x'], 2), ops.act(r['emb'].to(dev()), 'silu'), LR.GridState(2, 2, dev()))
+    close(to_vox(y, 2, 2), r['out'])
     r = G['lr']
     lr = load(LR.UNet3DModel(**C.TINY_LR_CFG), r['keys'])
     close(lr(x=r['x'].to(dev()), timesteps=r['t'].to(dev()), x_self_cond=r['x_self_cond'].to(dev())), r['out'], 1e-3)
+    close(lr(x=r['x'].to(dev()), timesteps=r['t'].to(dev())), r['out_nosc'], 1e-3)
     oc, doc = small(G['split_small'])
     m = G['lr_mid']
     close(lr.forward_as_middle(m['h'].to(dev()), doc, m['t'].to(dev()), None, None), m['out'], 1e-3)

@@ -52,68 +52,153 @@ extern "C" int ofx_grid_conv_table(int mode, int depth_out, int batch_size, int3
 // qkv row layout [rows, 3*C]: channel = head*3*ch + {q: 0..ch, k: ch..2ch, v: 2ch..3ch}
 // (the reference's reshape(b*heads, 3*ch, T), modules.py:531,540-541); out [rows, C] with
 // channel = head*ch + c.  scale ch^-1/4 on q and on k; softmax in fp32 over the keys.
-// One thread = one query; K/V tiles of 64 keys staged in LDS (broadcast reads); online
-// softmax across tiles.  Tiny work (<= 512 tokens): latency-, not throughput-, critical.
-template <int CH>
-__global__ void __launch_bounds__(128) attention_kernel(const float* __restrict__ qkv, int64_t ldq, int T, int heads, int ch,
-                                                        float* __restrict__ out, int64_t ldo) {
-  constexpr int KT = 64;
-  __shared__ __attribute__((aligned(16))) float Ks[KT * CH];
-  __shared__ __attribute__((aligned(16))) float Vs[KT * CH];
+//
+// fp32 MFMA (v_mfma_f32_32x32x2_f32), one wave = 32 queries, block = 4 waves = 128 queries,
+// K and V of the (batch, head) staged once in LDS.  The score tile is computed TRANSPOSED
+// (S^T = K Q^T): in the 32x32 C/D layout a lane then owns ONE query (its column) and 16 of
+// the tile's 32 keys, so the softmax reductions are in-lane plus one half-wave exchange, and
+// the probabilities feed the P.V MFMA straight from registers: the k-order of that MFMA is
+// permuted to the order in which the lanes already hold the keys (key(r,h) = (r&3) + 8(r>>2)
+// + 4h), which only changes which V row each lane reads.  Two passes over the keys (pass 1:
+// running max / sum per query; pass 2: P = exp(S - max)/sum, O += P V) -- no accumulator
+// rescaling, deterministic.
+typedef float f32x16d __attribute__((ext_vector_type(16)));
+
+template <int CH>   // CH = head channels rounded up to 32 (32, 64, 128)
+__global__ void __launch_bounds__(256, 1) attention_mfma_kernel(const float* __restrict__ qkv, int64_t ldq, int T,
+                                                                int heads, int ch, float* __restrict__ out,
+                                                                int64_t ldo) {
+  constexpr int KLD = CH + 4;                     // LDS row pitch (floats): conflict-free b128 reads over rows
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Tp = (T + 31) & ~31;                  // keys padded to whole 32-key tiles
+  float* Ks = smem;                               // [Tp][KLD]
+  float* Vs = smem + (size_t)Tp * KLD;            // [Tp][KLD]
   const int bh = blockIdx.x;
   const int b = bh / heads, hd = bh - b * heads;
-  const int t = blockIdx.y * blockDim.x + threadIdx.x;
-  const bool active = t < T;
   const int64_t row0 = (int64_t)b * T;
   const float scale = 1.f / sqrtf(sqrtf((float)ch));
-  float q[CH], o[CH];
-#pragma unroll
-  for (int c = 0; c < CH; ++c) { q[c] = 0.f; o[c] = 0.f; }
-  if (active) {
-    const float* qp = qkv + (row0 + t) * ldq + (int64_t)hd * 3 * ch;
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-      if (c < ch) q[c] = qp[c] * scale;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // stage K (pre-scaled) and V; zero the channel / key padding
+  const float* kbase = qkv + row0 * ldq + (int64_t)hd * 3 * ch + ch;
+  for (int i = threadIdx.x; i < Tp * CH; i += blockDim.x) {
+    const int s = i / CH, c = i - s * CH;
+    float kv = 0.f, vv = 0.f;
+    if (s < T && c < ch) {
+      const float* p = kbase + (int64_t)s * ldq + c;
+      kv = p[0] * scale;
+      vv = p[ch];
+    }
+    Ks[s * KLD + c] = kv;
+    Vs[s * KLD + c] = vv;
   }
+  __syncthreads();
+
+  const int q0 = blockIdx.y * 128 + wid * 32;      // this wave's 32 queries
+  if (q0 >= T) return;
+  const int qi = q0 + l31;                         // this lane's query (column of S^T)
+  const bool qok = qi < T;
+  // B operand of S^T = K Q^T: lane (query, h) holds Q[query][h*CH/2 + s], s < CH/2 (k-order permuted)
+  float qreg[CH / 2];
+  {
+    const float* qp = qkv + (row0 + (qok ? qi : T - 1)) * ldq + (int64_t)hd * 3 * ch;
+#pragma unroll
+    for (int s = 0; s < CH / 2; ++s) {
+      const int c = h * (CH / 2) + s;
+      qreg[s] = (c < ch) ? qp[c] * scale : 0.f;
+    }
+  }
+  const int ntile = Tp / 32;
+
+  auto score_tile = [&](int kt, f32x16d& st) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    const float* kr = Ks + (kt * 32 + l31) * KLD + h * (CH / 2);   // A operand: K[key = l31][h*CH/2 + s]
+#pragma unroll
+    for (int s4 = 0; s4 < CH / 8; ++s4) {
+      const float4 kv = *reinterpret_cast<const float4*>(kr + s4 * 4);
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qreg[s4 * 4 + 0], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qreg[s4 * 4 + 1], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qreg[s4 * 4 + 2], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qreg[s4 * 4 + 3], st, 0, 0, 0);
+    }
+    // mask padded keys: st[r] is key kt*32 + (r&3) + 8*(r>>2) + 4*h of this lane's query
+    if (kt * 32 + 32 > T) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= T) st[r] = -INFINITY;
+    }
+  };
+
+  // pass 1: per-query running max and sum of exp
   float mx = -INFINITY, den = 0.f;
-  for (int s0 = 0; s0 < T; s0 += KT) {
-    const int ns = T - s0 < KT ? T - s0 : KT;
-    __syncthreads();
-    for (int i = threadIdx.x; i < ns * ch; i += blockDim.x) {
-      const int s = i / ch, c = i - s * ch;
-      const float* kp = qkv + (row0 + s0 + s) * ldq + (int64_t)hd * 3 * ch + ch;
-      Ks[s * CH + c] = kp[c] * scale;
-      Vs[s * CH + c] = kp[ch + c];
-    }
-    __syncthreads();
-    if (active) {
-      for (int s = 0; s < ns; ++s) {
-        float w = 0.f;
+  for (int kt = 0; kt < ntile; ++kt) {
+    f32x16d st;
+    score_tile(kt, st);
+    float tm = st[0];
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
-          if (c < ch) w += q[c] * Ks[s * CH + c];
-        if (w > mx) {
-          const float f = __expf(mx - w);
-          den *= f;
+    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, st[r]);
+    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+    const float mn = fmaxf(mx, tm);
+    float ps = 0.f;
 #pragma unroll
-          for (int c = 0; c < CH; ++c) o[c] *= f;
-          mx = w;
-        }
-        const float p = __expf(w - mx);
-        den += p;
+    for (int r = 0; r < 16; ++r) ps += __expf(st[r] - mn);
+    ps += __shfl_xor(ps, 32, 64);
+    den = den * __expf(mx - mn) + ps;
+    mx = mn;
+  }
+  const float inv = 1.f / den;
+
+  // pass 2: O[query, c] += P[query, key] V[key, c]; A = P from registers, B = V rows key(r, h)
+  f32x16d oacc[CH / 32];
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
-          if (c < ch) o[c] += p * Vs[s * CH + c];
-      }
+  for (int j = 0; j < CH / 32; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[j][r] = 0.f;
+  for (int kt = 0; kt < ntile; ++kt) {
+    f32x16d st;
+    score_tile(kt, st);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = __expf(st[r] - mx) * inv;
+    const float* vr = Vs + (kt * 32 + 4 * h) * KLD + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* vrow = vr + ((r & 3) + 8 * (r >> 2)) * KLD;
+#pragma unroll
+      for (int j = 0; j < CH / 32; ++j)
+        oacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(st[r], vrow[j * 32], oacc[j], 0, 0, 0);
     }
   }
-  if (active) {
-    const float inv = 1.f / den;
-    float* op = out + (row0 + t) * ldo + (int64_t)hd * ch;
+  // O layout: lane (c = l31, h), reg r -> query q0 + (r&3) + 8(r>>2) + 4h
 #pragma unroll
-    for (int c = 0; c < CH; ++c)
-      if (c < ch) op[c] = o[c] * inv;
+  for (int j = 0; j < CH / 32; ++j) {
+    const int c = j * 32 + l31;
+    if (c >= ch) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (q < T) out[(row0 + q) * ldo + (int64_t)hd * ch + c] = oacc[j][r];
+    }
   }
+}
+
+template <int CH>
+static int launch_attention(const float* qkv, int64_t ldq, int B, int T, int heads, int ch, float* out, int64_t ldo,
+                            hipStream_t st) {
+  const int Tp = (T + 31) & ~31;
+  const size_t lds = (size_t)2 * Tp * (CH + 4) * sizeof(float);
+  if (lds > 160 * 1024) return OFX_EINVAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_kernel<CH>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return OFX_ELAUNCH;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(B * heads), (unsigned)ofx_cdiv(T, 128));
+  attention_mfma_kernel<CH><<<grid, 256, lds, st>>>(qkv, ldq, T, heads, ch, out, ldo);
+  return OFX_OK;
 }
 
 extern "C" int ofx_attention(const float* qkv, int64_t ldq, int batch_size, int T, int heads, int ch, float* out,
@@ -121,11 +206,12 @@ extern "C" int ofx_attention(const float* qkv, int64_t ldq, int batch_size, int 
   if (!qkv || !out || batch_size < 1 || T < 1 || heads < 1 || ch < 1 || ch > 128 || ldq < 3 * (int64_t)heads * ch ||
       ldo < (int64_t)heads * ch)
     return OFX_EINVAL;
-  dim3 grid((unsigned)(batch_size * heads), (unsigned)ofx_cdiv(T, 128));
   hipStream_t st = ofx_stream(stream);
-  if (ch <= 32) attention_kernel<32><<<grid, 128, 0, st>>>(qkv, ldq, T, heads, ch, out, ldo);
-  else if (ch <= 64) attention_kernel<64><<<grid, 128, 0, st>>>(qkv, ldq, T, heads, ch, out, ldo);
-  else attention_kernel<128><<<grid, 128, 0, st>>>(qkv, ldq, T, heads, ch, out, ldo);
+  int rc;
+  if (ch <= 32) rc = launch_attention<32>(qkv, ldq, batch_size, T, heads, ch, out, ldo, st);
+  else if (ch <= 64) rc = launch_attention<64>(qkv, ldq, batch_size, T, heads, ch, out, ldo, st);
+  else rc = launch_attention<128>(qkv, ldq, batch_size, T, heads, ch, out, ldo, st);
+  if (rc) return rc;
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }

@@ -364,8 +364,8 @@ __device__ __forceinline__ int64_t src_off(int32_t id, int64_t ldx, int64_t n_sr
   return i * ldx + (aux_delta & mask);
 }
 
-template <int WM, int WN, int MI, int NI>
-__global__ void __launch_bounds__(256, 2) gather_gemm_fast_kernel(const GemmArgs g) {
+template <int MODE, int WM, int WN, int MI, int NI>
+__global__ void __launch_bounds__(256, 2) gemm_fast_kernel(const GemmArgs g) {
   constexpr int BN = WN * NI * 32;
   constexpr int NB = BN / 32;
   static_assert(WM * MI * 32 == BM, "BM");
@@ -391,11 +391,11 @@ __global__ void __launch_bounds__(256, 2) gather_gemm_fast_kernel(const GemmArgs
   const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
 
   // wave-uniform operands, pinned in SGPRs
-  const gfp xp = (gfp)sgpr64((uint64_t)g.x);
+  const gfp xp = (gfp)sgpr64((uint64_t)(MODE == MODE_DENSE ? g.A : g.x));
   const gfp tfp = (gfp)sgpr64((uint64_t)g.tf);
   const gfp wp = (gfp)sgpr64((uint64_t)g.Wp);
   const gip tab = (gip)sgpr64((uint64_t)g.nbr_ext);
-  const int64_t ldx = (int64_t)sgpr64((uint64_t)g.ldx);
+  const int64_t ldx = (int64_t)sgpr64((uint64_t)(MODE == MODE_DENSE ? g.lda : g.ldx));
   const int64_t ldt = (int64_t)sgpr64((uint64_t)g.ldt), n_src = (int64_t)sgpr64((uint64_t)g.n_src);
   const int64_t Ncols = (int64_t)sgpr64((uint64_t)g.N);
   const int64_t aux_delta = (int64_t)sgpr64((uint64_t)((g.aux - g.x) - g.n_src * g.ldx));
@@ -412,8 +412,8 @@ __global__ void __launch_bounds__(256, 2) gather_gemm_fast_kernel(const GemmArgs
   const int nkt_all = (int)(g.Kp / BK);
   const int kt_begin = split * g.kt_per_split;
   const int kt_end = (kt_begin + g.kt_per_split < nkt_all) ? kt_begin + g.kt_per_split : nkt_all;
-  const int tpd = g.cin / BK;                    // k-tiles per direction
-  const int nkt_g = ndir * tpd;                  // gather tiles; tiles beyond are the type slab
+  const int tpd = MODE == MODE_DENSE ? nkt_all : g.cin / BK;      // k-tiles per direction
+  const int nkt_g = MODE == MODE_DENSE ? nkt_all : ndir * tpd;     // gather tiles; tiles beyond are the type slab
   const int g_begin = kt_begin < nkt_g ? kt_begin : nkt_g;
   const int g_end = kt_end < nkt_g ? kt_end : nkt_g;
   const int t_begin = kt_begin > nkt_g ? kt_begin : nkt_g;
@@ -427,6 +427,11 @@ __global__ void __launch_bounds__(256, 2) gather_gemm_fast_kernel(const GemmArgs
   const gip t1 = tab + m_1 * ndir;
   const gip t2 = tab + m_2 * ndir;
   const gip t3 = tab + m_3 * ndir;
+  // dense mode: fixed source rows (optional row map), K tail clamped (weights are zero-padded there)
+  int64_t dr0 = m_0, dr1 = m_1, dr2 = m_2, dr3 = m_3;
+  if (MODE == MODE_DENSE && g.a_rows) { dr0 = g.a_rows[m_0]; dr1 = g.a_rows[m_1]; dr2 = g.a_rows[m_2]; dr3 = g.a_rows[m_3]; }
+  const gfp dp0 = xp + dr0 * ldx, dp1 = xp + dr1 * ldx, dp2 = xp + dr2 * ldx, dp3 = xp + dr3 * ldx;
+  const int kclamp = (int)g.K - 4;
   int64_t bo0 = 0, bo1 = 0, bo2 = 0, bo3 = 0;
   {
     auto boff = [&](int i) {
@@ -454,13 +459,20 @@ __global__ void __launch_bounds__(256, 2) gather_gemm_fast_kernel(const GemmArgs
       const int d0 = g_begin / tpd;
       const int d1c = (g_begin + 1) / tpd;
       const int d1 = d1c < ndir ? d1c : ndir - 1;
-      ia0 = t0[d0]; ia1 = t1[d0]; ia2 = t2[d0]; ia3 = t3[d0];
-      ib0 = t0[d1]; ib1 = t1[d1]; ib2 = t2[d1]; ib3 = t3[d1];
-      const int cc = (g_begin - d0 * tpd) * BK + c4 * 4;
-      va0 = ldg4(xp + src_off(ia0, ldx, n_src, aux_delta) + cc);
-      va1 = ldg4(xp + src_off(ia1, ldx, n_src, aux_delta) + cc);
-      va2 = ldg4(xp + src_off(ia2, ldx, n_src, aux_delta) + cc);
-      va3 = ldg4(xp + src_off(ia3, ldx, n_src, aux_delta) + cc);
+      if (MODE == MODE_DENSE) {
+        ia0 = ia1 = ia2 = ia3 = ib0 = ib1 = ib2 = ib3 = 0;
+        int cc = g_begin * BK + c4 * 4;
+        cc = cc < kclamp ? cc : kclamp;
+        va0 = ldg4(dp0 + cc); va1 = ldg4(dp1 + cc); va2 = ldg4(dp2 + cc); va3 = ldg4(dp3 + cc);
+      } else {
+        ia0 = t0[d0]; ia1 = t1[d0]; ia2 = t2[d0]; ia3 = t3[d0];
+        ib0 = t0[d1]; ib1 = t1[d1]; ib2 = t2[d1]; ib3 = t3[d1];
+        const int cc = (g_begin - d0 * tpd) * BK + c4 * 4;
+        va0 = ldg4(xp + src_off(ia0, ldx, n_src, aux_delta) + cc);
+        va1 = ldg4(xp + src_off(ia1, ldx, n_src, aux_delta) + cc);
+        va2 = ldg4(xp + src_off(ia2, ldx, n_src, aux_delta) + cc);
+        va3 = ldg4(xp + src_off(ia3, ldx, n_src, aux_delta) + cc);
+      }
       const gfp wk = wp + (int64_t)g_begin * 8 * Ncols * 4;
       vb0 = ldg4(wk + bo0);
       if (NB > 1) vb1 = ldg4(wk + bo1);
@@ -483,12 +495,18 @@ __global__ void __launch_bounds__(256, 2) gather_gemm_fast_kernel(const GemmArgs
       const int dn = ktn / tpd;
       const int d2c = (kt + 2) / tpd;
       const int d2 = d2c < ndir ? d2c : ndir - 1;
-      ib0 = t0[d2]; ib1 = t1[d2]; ib2 = t2[d2]; ib3 = t3[d2];
-      const int cc = (ktn - dn * tpd) * BK + c4 * 4;
-      va0 = ldg4(xp + src_off(ia0, ldx, n_src, aux_delta) + cc);
-      va1 = ldg4(xp + src_off(ia1, ldx, n_src, aux_delta) + cc);
-      va2 = ldg4(xp + src_off(ia2, ldx, n_src, aux_delta) + cc);
-      va3 = ldg4(xp + src_off(ia3, ldx, n_src, aux_delta) + cc);
+      if (MODE == MODE_DENSE) {
+        int cc = ktn * BK + c4 * 4;
+        cc = cc < kclamp ? cc : kclamp;
+        va0 = ldg4(dp0 + cc); va1 = ldg4(dp1 + cc); va2 = ldg4(dp2 + cc); va3 = ldg4(dp3 + cc);
+      } else {
+        ib0 = t0[d2]; ib1 = t1[d2]; ib2 = t2[d2]; ib3 = t3[d2];
+        const int cc = (ktn - dn * tpd) * BK + c4 * 4;
+        va0 = ldg4(xp + src_off(ia0, ldx, n_src, aux_delta) + cc);
+        va1 = ldg4(xp + src_off(ia1, ldx, n_src, aux_delta) + cc);
+        va2 = ldg4(xp + src_off(ia2, ldx, n_src, aux_delta) + cc);
+        va3 = ldg4(xp + src_off(ia3, ldx, n_src, aux_delta) + cc);
+      }
       const gfp wk = wp + (int64_t)ktn * 8 * Ncols * 4;
       vb0 = ldg4(wk + bo0);
       if (NB > 1) vb1 = ldg4(wk + bo1);
@@ -557,7 +575,9 @@ __global__ void __launch_bounds__(256, 2) gather_gemm_fast_kernel(const GemmArgs
         float v = acc[i][j][r] + bv;
         if (g.emb) v += g.emb[(int64_t)g.bid[m] * g.lde + n];
         if (g.res) v += g.res[m * g.ldr + n];
-        g.out[m * g.ldc + n] = v;
+        int64_t om = m;
+        if (g.out_rows) { om = g.out_rows[m]; if (om < 0) continue; }
+        g.out[om * g.ldc + n] = v;
       }
     }
   }
@@ -616,18 +636,18 @@ static int launch_cfg(GemmArgs& g, hipStream_t st) {
   return OFX_OK;
 }
 
-template <int WM, int WN, int MI, int NI>
+template <int MODE, int WM, int WN, int MI, int NI>
 static int launch_fast_cfg(GemmArgs& g, hipStream_t st) {
   constexpr int BN = WN * NI * 32;
   constexpr size_t lds = (2 * BM * A_LD + 2 * 8 * BN * 4) * sizeof(float);
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_gemm_fast_kernel<WM, WN, MI, NI>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<MODE, WM, WN, MI, NI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return OFX_ELAUNCH;
     attr_set = true;
   }
-  gather_gemm_fast_kernel<WM, WN, MI, NI><<<g.ntm * g.ntn * g.nsplit, 256, lds, st>>>(g);
+  gemm_fast_kernel<MODE, WM, WN, MI, NI><<<g.ntm * g.ntn * g.nsplit, 256, lds, st>>>(g);
   return OFX_OK;
 }
 
@@ -654,11 +674,17 @@ static int launch_gemm(GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st) 
   g.nsplit = nsplit;
   g.ws = ws;
   int rc;
-  const bool fast = MODE == MODE_GATHER && g.fast && g.nbr_ext && g.aux && !g.out_rows;
+  bool fast;
+  if (MODE == MODE_GATHER) {
+    fast = g.fast && g.nbr_ext && g.aux && !g.out_rows;
+  } else {
+    fast = ((g.lda & 3) == 0) && ((g.K & 3) == 0) && g.K >= 4 && ((((uintptr_t)g.A) & 15) == 0);
+    if (fast) { g.ndir = 1; g.n_src = 0; g.aux = g.A; g.tf = g.A; g.ldt = g.lda; g.nbr_ext = (const int32_t*)g.A; }
+  }
   if (fast) {
-    if (bn == 32) rc = launch_fast_cfg<4, 1, 1, 1>(g, st);
-    else if (bn == 64) rc = launch_fast_cfg<2, 2, 2, 1>(g, st);
-    else rc = launch_fast_cfg<2, 2, 2, 2>(g, st);
+    if (bn == 32) rc = launch_fast_cfg<MODE, 4, 1, 1, 1>(g, st);
+    else if (bn == 64) rc = launch_fast_cfg<MODE, 2, 2, 2, 1>(g, st);
+    else rc = launch_fast_cfg<MODE, 2, 2, 2, 2>(g, st);
   } else if (bn == 32) rc = launch_cfg<MODE, 4, 1, 1, 1>(g, st);
   else if (bn == 64) rc = launch_cfg<MODE, 2, 2, 2, 1>(g, st);
   else rc = launch_cfg<MODE, 2, 2, 2, 2>(g, st);

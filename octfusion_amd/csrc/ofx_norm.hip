@@ -10,7 +10,10 @@
 // fp64, rstd = 1/sqrt(var + eps).
 #include "ofx_common.h"
 
-constexpr int GN_ROWS_PER_BLOCK = 512;
+// 64 rows per block: the kernel is latency/MLP-bound, not atomic-bound -- it needs >> 256 CUs x 8
+// resident blocks with several 16-B loads in flight per lane (a 512-row block left 1.6 blocks per CU
+// and ~0.85 TB/s).  Each block reduces its rows in LDS and issues one fp64 atomic pair per channel.
+constexpr int GN_ROWS_PER_BLOCK = 64;
 
 __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int C,
                                                        const int32_t* __restrict__ bid, double* __restrict__ sums) {
@@ -28,23 +31,32 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
     double* o = sums + ((int64_t)b * C + cl * 4) * 2;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      atomicAdd(o + 2 * k, (double)ps[k]);
-      atomicAdd(o + 2 * k + 1, (double)pq[k]);
+      unsafeAtomicAdd(o + 2 * k, (double)ps[k]);      // hardware global_atomic_add_f64 (no CAS loop)
+      unsafeAtomicAdd(o + 2 * k + 1, (double)pq[k]);
     }
   };
-  if (rl < RP) {
-    for (int64_t r = r_begin + rl; r < r_end; r += RP) {
-      const int b = bid[r];
-      if (b != cb) {
-        flush_direct(cb, s, q);
-        cb = b;
-        s[0] = s[1] = s[2] = s[3] = 0.f;
-        q[0] = q[1] = q[2] = q[3] = 0.f;
-      }
-      const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + cl * 4);
-      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-      q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+  auto accum = [&](int b, const float4& v) {
+    if (b != cb) {
+      flush_direct(cb, s, q);
+      cb = b;
+      s[0] = s[1] = s[2] = s[3] = 0.f;
+      q[0] = q[1] = q[2] = q[3] = 0.f;
     }
+    s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+  };
+  if (rl < RP) {
+    int64_t r = r_begin + rl;
+    // 4 independent 16-B loads in flight per lane
+    for (; r + 3 * (int64_t)RP < r_end; r += 4 * (int64_t)RP) {
+      const int b0 = bid[r], b1 = bid[r + RP], b2 = bid[r + 2 * RP], b3 = bid[r + 3 * RP];
+      const float4 v0 = *reinterpret_cast<const float4*>(x + r * ldx + cl * 4);
+      const float4 v1 = *reinterpret_cast<const float4*>(x + (r + RP) * ldx + cl * 4);
+      const float4 v2 = *reinterpret_cast<const float4*>(x + (r + 2 * RP) * ldx + cl * 4);
+      const float4 v3 = *reinterpret_cast<const float4*>(x + (r + 3 * RP) * ldx + cl * 4);
+      accum(b0, v0); accum(b1, v1); accum(b2, v2); accum(b3, v3);
+    }
+    for (; r < r_end; r += RP) accum(bid[r], *reinterpret_cast<const float4*>(x + r * ldx + cl * 4));
   }
   sb[threadIdx.x] = (rl < RP) ? cb : -1;
 #pragma unroll
@@ -66,7 +78,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
     if (cb >= 0) {
       double* o = sums + ((int64_t)cb * C + cl * 4) * 2;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { atomicAdd(o + 2 * k, ds[k]); atomicAdd(o + 2 * k + 1, dq[k]); }
+      for (int k = 0; k < 4; ++k) { unsafeAtomicAdd(o + 2 * k, ds[k]); unsafeAtomicAdd(o + 2 * k + 1, dq[k]); }
     }
   }
 }

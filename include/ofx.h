@@ -152,6 +152,15 @@ int ofx_graph_type_frac(const int32_t* seg_ptr, const int32_t* col, const uint8_
  * transposed nn.Linear [N,K] (sk = 1, sn = K) and -- when cin > 0 -- the
  * GraphConv row permutation: reference row dir*(cin+nt)+c (modules.py:174-176)
  * -> packed k = dir*cin + c for features, 7*cin + dir*nt + t for node types. */
+/* Contraction precision (process-wide): 0 = bf16x3 (default): activations and weights are
+ * split into bf16 hi+lo pairs and a*w = a_hi*w_hi + a_lo*w_hi + a_hi*w_lo runs on the bf16
+ * matrix pipe with fp32 accumulation -- ~1e-5 relative to an fp32 reference at 16/3 x the
+ * fp32-MFMA rate; 1 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-equal to an fma chain).
+ * A packed-weight buffer holds the fp32 pack followed by the bf16 hi|lo planes:
+ * ofx_packed_floats(Kp, N) floats in total. */
+int ofx_set_precision(int mode);
+int ofx_get_precision(void);
+int64_t ofx_packed_floats(int64_t Kp, int64_t N);
 int64_t ofx_packed_k(int64_t K);                       /* K rounded up to 32 */
 int64_t ofx_graphconv_packed_k(int cin, int nt);       /* 7*cin + pad32(7*nt)  */
 int ofx_pack_weights(const float* W, int64_t sk, int64_t sn, int64_t K, int64_t N,

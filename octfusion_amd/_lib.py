@@ -48,6 +48,9 @@ _SIGS = {
     'ofx_graph_fill': (c_i, [ctypes.POINTER(OfxTree), c_i, c_p, c_p, c_p], True),
     'ofx_graph_expand': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_p], True),
     'ofx_graph_type_frac': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_l, c_p], True),
+    'ofx_set_precision': (c_i, [c_i], True),
+    'ofx_get_precision': (c_i, [], False),
+    'ofx_packed_floats': (c_l, [c_l, c_l], False),
     'ofx_packed_k': (c_l, [c_l], False),
     'ofx_graphconv_packed_k': (c_l, [c_i, c_i], False),
     'ofx_pack_weights': (c_i, [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_p, c_l, c_p], True),

@@ -44,6 +44,7 @@ struct GemmArgs {
   // common
   int64_t M, K;            // K: logical K for dense bounds; gather uses Kp only
   const float* Wp; int64_t Kp, N;
+  const uint16_t* W16;     // bf16 hi | lo split of the packed weights ([k/8][n][8] each), or NULL
   const float* bias;
   const float* emb; int64_t lde; const int32_t* bid;
   const float* res; int64_t ldr;
@@ -583,6 +584,317 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(const GemmArgs g) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------
+// bf16x3 contraction: fp32-class accuracy on the bf16 matrix pipe (16x the fp32 MFMA rate).
+//   a = a_hi + a_lo, w = w_hi + w_lo (bf16 pairs, round-to-nearest-even);
+//   a*w ~= a_hi*w_hi + a_lo*w_hi + a_hi*w_lo   (dropped a_lo*w_lo <= 2^-18 |a w|),
+// every product exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16: per-product relative
+// error <= ~2^-16 (1.5e-5), i.e. the result agrees with an fp32 reference to ~1e-5 -- inside the
+// 1e-3 parity bar with two orders of magnitude to spare, at 16/3 = 5.3x the fp32 MFMA rate.
+// Same pipeline as gemm_fast_kernel (branch-free gather, indices two tiles ahead, rows one tile
+// ahead, pinned issue order); activations are split when they are written to LDS, weights are
+// pre-split once by the pack kernels.  LDS per buffer: A_hi/A_lo [128][32+8] bf16 (80-B rows:
+// conflict-free b128 reads), B_hi/B_lo [4][BN][8] bf16.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void split_bf16x4(const float4& v, uint2& hi, uint2& lo) {
+  hi.x = cvt_pk_bf16(v.x, v.y);
+  hi.y = cvt_pk_bf16(v.z, v.w);
+  const float hx = __uint_as_float(hi.x << 16), hy = __uint_as_float(hi.x & 0xffff0000u);
+  const float hz = __uint_as_float(hi.y << 16), hw = __uint_as_float(hi.y & 0xffff0000u);
+  lo.x = cvt_pk_bf16(v.x - hx, v.y - hy);
+  lo.y = cvt_pk_bf16(v.z - hz, v.w - hw);
+}
+
+template <int MODE, int WM, int WN, int MI, int NI>
+__global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
+  constexpr int BN = WN * NI * 32;
+  constexpr int NBQ = BN >= 64 ? BN / 64 : 1;           // 16-B weight chunks per thread per (hi|lo) tile
+  constexpr int A_BYTES = BM * 80;                      // one A plane (hi or lo)
+  constexpr int B_BYTES = 4 * BN * 16;                  // one B plane
+  constexpr int BUF_BYTES = 2 * A_BYTES + 2 * B_BYTES;
+  static_assert(WM * MI * 32 == BM, "BM");
+  extern __shared__ __attribute__((aligned(16))) char smem8[];
+
+  const int ntile = g.ntm * g.ntn;
+  const int nblk = ntile * g.nsplit;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, j = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int split = bid / ntile;
+  bid -= split * ntile;
+  const int tm = bid / g.ntn, tn = bid - tm * g.ntn;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+
+  const gfp xp = (gfp)sgpr64((uint64_t)(MODE == MODE_DENSE ? g.A : g.x));
+  const gfp tfp = (gfp)sgpr64((uint64_t)g.tf);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef const u32x4 __attribute__((address_space(1)))* gqp;
+  const gqp w16 = (gqp)sgpr64((uint64_t)g.W16);
+  const gip tab = (gip)sgpr64((uint64_t)g.nbr_ext);
+  const int64_t ldx = (int64_t)sgpr64((uint64_t)(MODE == MODE_DENSE ? g.lda : g.ldx));
+  const int64_t ldt = (int64_t)sgpr64((uint64_t)g.ldt), n_src = (int64_t)sgpr64((uint64_t)g.n_src);
+  const int64_t Ncols = (int64_t)sgpr64((uint64_t)g.N);
+  const int64_t lo_off = (int64_t)sgpr64((uint64_t)(g.Kp / 8 * g.N));     // uint4 units: hi plane -> lo plane
+  const int64_t aux_delta = (int64_t)sgpr64((uint64_t)((g.aux - g.x) - g.n_src * g.ldx));
+  const int ndir = g.ndir;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nkt_all = (int)(g.Kp / BK);
+  const int kt_begin = split * g.kt_per_split;
+  const int kt_end = (kt_begin + g.kt_per_split < nkt_all) ? kt_begin + g.kt_per_split : nkt_all;
+  const int tpd = MODE == MODE_DENSE ? nkt_all : g.cin / BK;
+  const int nkt_g = MODE == MODE_DENSE ? nkt_all : ndir * tpd;
+  const int g_begin = kt_begin < nkt_g ? kt_begin : nkt_g;
+  const int g_end = kt_end < nkt_g ? kt_end : nkt_g;
+  const int t_begin = kt_begin > nkt_g ? kt_begin : nkt_g;
+
+  int64_t m_0 = m0 + r0, m_1 = m_0 + 32, m_2 = m_0 + 64, m_3 = m_0 + 96;
+  const int64_t mmax = g.M - 1;
+  m_0 = m_0 < mmax ? m_0 : mmax; m_1 = m_1 < mmax ? m_1 : mmax;
+  m_2 = m_2 < mmax ? m_2 : mmax; m_3 = m_3 < mmax ? m_3 : mmax;
+  const gip t0 = tab + m_0 * ndir;
+  const gip t1 = tab + m_1 * ndir;
+  const gip t2 = tab + m_2 * ndir;
+  const gip t3 = tab + m_3 * ndir;
+  int64_t dr0 = m_0, dr1 = m_1, dr2 = m_2, dr3 = m_3;
+  if (MODE == MODE_DENSE && g.a_rows) { dr0 = g.a_rows[m_0]; dr1 = g.a_rows[m_1]; dr2 = g.a_rows[m_2]; dr3 = g.a_rows[m_3]; }
+  const gfp dp0 = xp + dr0 * ldx, dp1 = xp + dr1 * ldx, dp2 = xp + dr2 * ldx, dp3 = xp + dr3 * ldx;
+  const int kclamp = (int)g.K - 4;
+
+  // weight chunk offsets (uint4 units inside one plane of one k-tile): chunk q = kgroup*BN + n
+  int64_t bo[NBQ];
+  const bool b_active = (BN >= 64) || threadIdx.x < 4 * BN;
+#pragma unroll
+  for (int i = 0; i < NBQ; ++i) {
+    int q = threadIdx.x + 256 * i;
+    q = q < 4 * BN ? q : 4 * BN - 1;
+    int64_t nn = n0 + q % BN;
+    nn = nn < Ncols ? nn : Ncols - 1;
+    bo[i] = (int64_t)(q / BN) * Ncols + nn;
+  }
+  char* const a_st = smem8 + (r0 * 80 + c4 * 8);
+  char* const b_st = smem8 + 2 * A_BYTES + threadIdx.x * 16;
+  const char* const a_ld = smem8 + ((wm * MI * 32 + l31) * 80 + 16 * h);
+  const char* const b_ld = smem8 + 2 * A_BYTES + ((h * BN + wn * NI * 32 + l31) * 16);
+
+  float4 va0, va1, va2, va3;
+  u32x4 wh[NBQ], wl[NBQ];
+
+  auto load_w = [&](int kt) {
+    const gqp wk = w16 + (int64_t)kt * 4 * Ncols;
+#pragma unroll
+    for (int i = 0; i < NBQ; ++i) { wh[i] = wk[bo[i]]; wl[i] = wk[lo_off + bo[i]]; }
+  };
+  auto store_tiles = [&](int buf) {
+    char* a = a_st + buf * BUF_BYTES;
+    uint2 hi, lo;
+    split_bf16x4(va0, hi, lo);
+    *reinterpret_cast<uint2*>(a) = hi; *reinterpret_cast<uint2*>(a + A_BYTES) = lo;
+    split_bf16x4(va1, hi, lo);
+    *reinterpret_cast<uint2*>(a + 32 * 80) = hi; *reinterpret_cast<uint2*>(a + 32 * 80 + A_BYTES) = lo;
+    split_bf16x4(va2, hi, lo);
+    *reinterpret_cast<uint2*>(a + 64 * 80) = hi; *reinterpret_cast<uint2*>(a + 64 * 80 + A_BYTES) = lo;
+    split_bf16x4(va3, hi, lo);
+    *reinterpret_cast<uint2*>(a + 96 * 80) = hi; *reinterpret_cast<uint2*>(a + 96 * 80 + A_BYTES) = lo;
+    if (b_active) {
+      char* b = b_st + buf * BUF_BYTES;
+#pragma unroll
+      for (int i = 0; i < NBQ; ++i) {
+        *reinterpret_cast<u32x4*>(b + i * 4096) = wh[i];
+        *reinterpret_cast<u32x4*>(b + i * 4096 + B_BYTES) = wl[i];
+      }
+    }
+  };
+  auto compute = [&](int buf) {
+    const char* a = a_ld + buf * BUF_BYTES;
+    const char* b = b_ld + buf * BUF_BYTES;
+    bf16x8_t ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      ah[0][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80);
+      al[0][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + A_BYTES);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      bh[0][j] = *reinterpret_cast<const bf16x8_t*>(b + j * 32 * 16);
+      bl[0][j] = *reinterpret_cast<const bf16x8_t*>(b + j * 32 * 16 + B_BYTES);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c == 0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          ah[1][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + 32);
+          al[1][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + 32 + A_BYTES);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          bh[1][j] = *reinterpret_cast<const bf16x8_t*>(b + (2 * BN + j * 32) * 16);
+          bl[1][j] = *reinterpret_cast<const bf16x8_t*>(b + (2 * BN + j * 32) * 16 + B_BYTES);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[c][i], bh[c][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c][i], bl[c][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c][i], bh[c][j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  // ------------------------------------------------------------ gather / dense tiles
+  if (g_begin < g_end) {
+    int32_t ia0 = 0, ia1 = 0, ia2 = 0, ia3 = 0, ib0 = 0, ib1 = 0, ib2 = 0, ib3 = 0;
+    if (MODE == MODE_DENSE) {
+      int cc = g_begin * BK + c4 * 4;
+      cc = cc < kclamp ? cc : kclamp;
+      va0 = ldg4(dp0 + cc); va1 = ldg4(dp1 + cc); va2 = ldg4(dp2 + cc); va3 = ldg4(dp3 + cc);
+    } else {
+      const int d0 = g_begin / tpd;
+      const int d1c = (g_begin + 1) / tpd;
+      const int d1 = d1c < ndir ? d1c : ndir - 1;
+      ia0 = t0[d0]; ia1 = t1[d0]; ia2 = t2[d0]; ia3 = t3[d0];
+      ib0 = t0[d1]; ib1 = t1[d1]; ib2 = t2[d1]; ib3 = t3[d1];
+      const int cc = (g_begin - d0 * tpd) * BK + c4 * 4;
+      va0 = ldg4(xp + src_off(ia0, ldx, n_src, aux_delta) + cc);
+      va1 = ldg4(xp + src_off(ia1, ldx, n_src, aux_delta) + cc);
+      va2 = ldg4(xp + src_off(ia2, ldx, n_src, aux_delta) + cc);
+      va3 = ldg4(xp + src_off(ia3, ldx, n_src, aux_delta) + cc);
+    }
+    load_w(g_begin);
+    store_tiles(0);
+    ia0 = ib0; ia1 = ib1; ia2 = ib2; ia3 = ib3;
+    __syncthreads();
+
+    for (int kt = g_begin; kt < g_end; ++kt) {
+      const int buf = (kt - g_begin) & 1;
+      const int ktn = kt + 1 < nkt_g ? kt + 1 : nkt_g - 1;
+      if (MODE == MODE_DENSE) {
+        int cc = ktn * BK + c4 * 4;
+        cc = cc < kclamp ? cc : kclamp;
+        va0 = ldg4(dp0 + cc); va1 = ldg4(dp1 + cc); va2 = ldg4(dp2 + cc); va3 = ldg4(dp3 + cc);
+      } else {
+        const int dn = ktn / tpd;
+        const int d2c = (kt + 2) / tpd;
+        const int d2 = d2c < ndir ? d2c : ndir - 1;
+        ib0 = t0[d2]; ib1 = t1[d2]; ib2 = t2[d2]; ib3 = t3[d2];
+        const int cc = (ktn - dn * tpd) * BK + c4 * 4;
+        va0 = ldg4(xp + src_off(ia0, ldx, n_src, aux_delta) + cc);
+        va1 = ldg4(xp + src_off(ia1, ldx, n_src, aux_delta) + cc);
+        va2 = ldg4(xp + src_off(ia2, ldx, n_src, aux_delta) + cc);
+        va3 = ldg4(xp + src_off(ia3, ldx, n_src, aux_delta) + cc);
+      }
+      load_w(ktn);
+      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above the MFMA block (see gemm_fast_kernel)
+      compute(buf);
+      __builtin_amdgcn_sched_barrier(0);
+      store_tiles(buf ^ 1);
+      ia0 = ib0; ia1 = ib1; ia2 = ib2; ia3 = ib3;
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------ node-type slab tiles
+  for (int kt = t_begin; kt < kt_end; ++kt) {
+    const int cc = (kt - nkt_g) * BK + c4 * 4;
+    va0 = ldg4(tfp + m_0 * ldt + cc);
+    va1 = ldg4(tfp + m_1 * ldt + cc);
+    va2 = ldg4(tfp + m_2 * ldt + cc);
+    va3 = ldg4(tfp + m_3 * ldt + cc);
+    load_w(kt);
+    store_tiles(0);
+    __syncthreads();
+    compute(0);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int64_t n = n0 + (wn * NI + j) * 32 + l31;
+      if (n >= g.N) continue;
+      if (g.nsplit > 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < g.M) g.ws[((int64_t)split * g.M + m) * g.N + n] = acc[i][j][r];
+        }
+        continue;
+      }
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (g.emb) v += g.emb[(int64_t)g.bid[m] * g.lde + n];
+        if (g.res) v += g.res[m * g.ldr + n];
+        int64_t om = m;
+        if (g.out_rows) { om = g.out_rows[m]; if (om < 0) continue; }
+        g.out[om * g.ldc + n] = v;
+      }
+    }
+  }
+}
+
+// split the fp32-packed weights [k/4][n][4] into bf16 hi | lo planes, each [k/8][n][8]
+__device__ __forceinline__ uint32_t bf16_rne_bits(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__global__ void pack_bf16x3_kernel(const float* __restrict__ Wp, int64_t Kp, int64_t N, uint16_t* __restrict__ W16) {
+  const int64_t total = Kp * N;            // one element per (k, n)
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t kg = t / (N * 8), rem = t - kg * N * 8;
+    const int64_t n = rem / 8;
+    const int kk = (int)(rem - n * 8);
+    const int64_t k = kg * 8 + kk;
+    const float w = Wp[((k >> 2) * N + n) * 4 + (k & 3)];
+    const uint32_t hi = bf16_rne_bits(w);
+    const float wl = w - __uint_as_float(hi << 16);
+    W16[t] = (uint16_t)hi;
+    W16[total + t] = (uint16_t)bf16_rne_bits(wl);
+  }
+}
+static int pack_bf16x3(const float* Wp, int64_t Kp, int64_t N, hipStream_t st) {
+  uint16_t* W16 = reinterpret_cast<uint16_t*>(const_cast<float*>(Wp) + Kp * N);
+  pack_bf16x3_kernel<<<ofx_grid(Kp * N, 256), 256, 0, st>>>(Wp, Kp, N, W16);
+  return OFX_OK;
+}
+
+static int g_precision = 0;     // 0: bf16x3 on the bf16 matrix pipe (default), 1: exact fp32 MFMA
+extern "C" int ofx_set_precision(int mode) {
+  if (mode != 0 && mode != 1) return OFX_EINVAL;
+  g_precision = mode;
+  return OFX_OK;
+}
+extern "C" int ofx_get_precision(void) { return g_precision; }
+extern "C" int64_t ofx_packed_floats(int64_t Kp, int64_t N) { return 2 * Kp * N; }
+
 // aux[0, :] = 0; aux[1 + v, :] = mean over segment multi_seg[v] of x[col, :]
 __global__ void __launch_bounds__(256) multi_mean_kernel(const float* __restrict__ x, int64_t ldx, int cin,
                                                          const int32_t* __restrict__ seg_ptr,
@@ -651,6 +963,21 @@ static int launch_fast_cfg(GemmArgs& g, hipStream_t st) {
   return OFX_OK;
 }
 
+template <int MODE, int WM, int WN, int MI, int NI>
+static int launch_bf16x3_cfg(GemmArgs& g, hipStream_t st) {
+  constexpr int BN = WN * NI * 32;
+  constexpr size_t lds = 2 * (2 * BM * 80 + 2 * 4 * BN * 16);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<MODE, WM, WN, MI, NI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return OFX_ELAUNCH;
+    attr_set = true;
+  }
+  gemm_bf16x3_kernel<MODE, WM, WN, MI, NI><<<g.ntm * g.ntn * g.nsplit, 256, lds, st>>>(g);
+  return OFX_OK;
+}
+
 template <int MODE>
 static int launch_gemm(GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0) return OFX_OK;
@@ -681,7 +1008,12 @@ static int launch_gemm(GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st) 
     fast = ((g.lda & 3) == 0) && ((g.K & 3) == 0) && g.K >= 4 && ((((uintptr_t)g.A) & 15) == 0);
     if (fast) { g.ndir = 1; g.n_src = 0; g.aux = g.A; g.tf = g.A; g.ldt = g.lda; g.nbr_ext = (const int32_t*)g.A; }
   }
-  if (fast) {
+  g.W16 = (g_precision == 0) ? reinterpret_cast<const uint16_t*>(g.Wp + g.Kp * g.N) : nullptr;
+  if (fast && g.W16) {
+    if (bn == 32) rc = launch_bf16x3_cfg<MODE, 4, 1, 1, 1>(g, st);
+    else if (bn == 64) rc = launch_bf16x3_cfg<MODE, 2, 2, 2, 1>(g, st);
+    else rc = launch_bf16x3_cfg<MODE, 2, 2, 2, 2>(g, st);
+  } else if (fast) {
     if (bn == 32) rc = launch_fast_cfg<MODE, 4, 1, 1, 1>(g, st);
     else if (bn == 64) rc = launch_fast_cfg<MODE, 2, 2, 2, 1>(g, st);
     else rc = launch_fast_cfg<MODE, 2, 2, 2, 2>(g, st);
@@ -695,6 +1027,7 @@ static int launch_gemm(GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st) 
 }
 
 static inline int64_t pad32(int64_t v) { return (v + 31) / 32 * 32; }
+static int pack_bf16x3(const float* Wp, int64_t Kp, int64_t N, hipStream_t st);
 
 extern "C" int64_t ofx_packed_k(int64_t K) { return pad32(K); }
 extern "C" int64_t ofx_graphconv_packed_k(int cin, int nt) {
@@ -740,6 +1073,7 @@ extern "C" int ofx_pack_weights(const float* W, int64_t sk, int64_t sn, int64_t 
   }
   if (((uintptr_t)Wp & 15) != 0) return OFX_EINVAL;
   pack_weights_kernel<<<ofx_grid((Kp / 4) * N, 256), 256, 0, ofx_stream(stream)>>>(W, sk, sn, K, N, cin, nt, Wp, Kp);
+  pack_bf16x3(Wp, Kp, N, ofx_stream(stream));
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
@@ -770,6 +1104,7 @@ extern "C" int ofx_pack_conv3d(const float* W, int cin, int cout, float* Wp, voi
   if (!W || !Wp || cin < 1 || cout < 1 || ((uintptr_t)Wp & 15)) return OFX_EINVAL;
   const int64_t Kp = ofx_conv3d_packed_k(cin);
   pack_conv3d_kernel<<<ofx_grid((Kp / 4) * cout, 256), 256, 0, ofx_stream(stream)>>>(W, cin, cout, Wp, Kp);
+  pack_bf16x3(Wp, Kp, cout, ofx_stream(stream));
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }

@@ -42,6 +42,11 @@ def _row_major(t):
 _WS = {}
 
 
+def set_precision(mode):
+    """'bf16x3' (default: fp32-class accuracy on the bf16 matrix pipe) or 'fp32' (exact fp32 MFMA)."""
+    call('ofx_set_precision', {'bf16x3': 0, 'fp32': 1}[mode])
+
+
 def workspace(device, nbytes=64 << 20):
     """Per-device split-K scratch (partial tiles); reused by every launch on the stream."""
     key = (device.type, device.index)
@@ -93,7 +98,7 @@ class PackedWeight:
         else:
             cin = nt = 0
             Kp = L.ofx_packed_k(K)
-        out = torch.empty((Kp // 4) * N * 4, dtype=torch.float32, device=w.device)
+        out = torch.empty(L.ofx_packed_floats(Kp, N), dtype=torch.float32, device=w.device)
         call('ofx_pack_weights', ptr(w), sk, sn, K, N, cin, nt, ptr(out), Kp, stream())
         self.t, self.key, self.K, self.N, self.Kp = out, key, K, N, Kp
         return self
@@ -198,7 +203,7 @@ class PackedConv3d:
         assert tuple(w.shape[2:]) == (3, 3, 3)
         w = w.detach().contiguous()
         Kp = _lib.lib().ofx_conv3d_packed_k(cin)
-        out = torch.empty((Kp // 4) * cout * 4, dtype=torch.float32, device=w.device)
+        out = torch.empty(_lib.lib().ofx_packed_floats(Kp, cout), dtype=torch.float32, device=w.device)
         call('ofx_pack_conv3d', ptr(w), cin, cout, ptr(out), stream())
         self.t, self.key, self.cin, self.N = out, key, cin, cout
         return self

@@ -282,6 +282,35 @@ def test_gridconv_vs_torch():
         close(to_vox(y, B, m.out_depth(d)), ref)
 
 
+def test_precision_modes_vs_oracle():
+    """bf16x3 (default) and exact-fp32 contraction both meet the bar; bf16x3 stays ~1e-5 from fp32."""
+    from octfusion_amd import modules as M, ops
+    from oracle import dual_octree as OD, modules as OM, sampler as OS
+    split = C.random_split_small(2, 3, 33, p=0.45)
+    oc, doc = small(split)
+    o_oc = OS.split2octree_small(split, 5, 3)
+    o_doc = OD.OracleDualOctree(o_oc)
+    o_doc.post_processing_for_docnn()
+    m = M.GraphConv(128, 128, 7, 7, 4)
+    sd = C.fill_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()])
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    x = C.rand_input('prec', doc.csr(5)[2], 128)
+    ref = OM.graph_conv(x.double(), o_doc, 5, sd['weights'].double(), None, 4).float()
+    try:
+        ops.set_precision('fp32')
+        y32 = m(x.to(dev()), doc, 5).cpu()
+        ops.set_precision('bf16x3')
+        y16 = m(x.to(dev()), doc, 5).cpu()
+    finally:
+        ops.set_precision('bf16x3')
+    scale = float(ref.abs().max())
+    e32 = float((y32 - ref).abs().max()) / scale
+    e16 = float((y16 - ref).abs().max()) / scale
+    assert e32 < 5e-6, e32
+    assert e16 < 5e-5, e16
+
+
 def test_dense_and_unet(golden):
     from octfusion_amd import graph_unet_lr as LR, graph_unet_union as U, ops
     G = golden('g_dense')

@@ -359,8 +359,10 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ a, const flo
 
 // element offset (from x) of source row `id`: rows >= n_src live in aux (same row pitch ldx);
 // pure ALU (no select on pointers) so hipcc cannot turn it into a branch or a kernarg re-load.
-__device__ __forceinline__ int64_t src_off(int32_t id, int64_t ldx, int64_t n_src, int64_t aux_delta) {
-  const int64_t i = id;
+__device__ __forceinline__ int64_t src_off(uint32_t id, int64_t ldx, int64_t n_src, int64_t aux_delta) {
+  // ids are non-negative: zero-extension costs no instruction that depends on the loaded value (a sign
+  // extension would be hoisted next to the load and force an early s_waitcnt on the index prefetch)
+  const int64_t i = (int64_t)(uint64_t)id;
   const int64_t mask = (n_src - 1 - i) >> 63;           // all ones iff id >= n_src
   return i * ldx + (aux_delta & mask);
 }
@@ -457,9 +459,9 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(const GemmArgs g) {
   if (g_begin < g_end) {
     int32_t ia0, ia1, ia2, ia3, ib0, ib1, ib2, ib3;
     {
-      const int d0 = g_begin / tpd;
-      const int d1c = (g_begin + 1) / tpd;
-      const int d1 = d1c < ndir ? d1c : ndir - 1;
+      // iteration order: channel chunk outer, direction inner (see gemm_bf16x3_kernel)
+      const int d0 = g_begin % ndir;
+      const int d1 = (g_begin + 1 < nkt_g ? g_begin + 1 : nkt_g - 1) % ndir;
       if (MODE == MODE_DENSE) {
         ia0 = ia1 = ia2 = ia3 = ib0 = ib1 = ib2 = ib3 = 0;
         int cc = g_begin * BK + c4 * 4;
@@ -468,13 +470,14 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(const GemmArgs g) {
       } else {
         ia0 = t0[d0]; ia1 = t1[d0]; ia2 = t2[d0]; ia3 = t3[d0];
         ib0 = t0[d1]; ib1 = t1[d1]; ib2 = t2[d1]; ib3 = t3[d1];
-        const int cc = (g_begin - d0 * tpd) * BK + c4 * 4;
+        const int cc = (g_begin / ndir) * BK + c4 * 4;
         va0 = ldg4(xp + src_off(ia0, ldx, n_src, aux_delta) + cc);
         va1 = ldg4(xp + src_off(ia1, ldx, n_src, aux_delta) + cc);
         va2 = ldg4(xp + src_off(ia2, ldx, n_src, aux_delta) + cc);
         va3 = ldg4(xp + src_off(ia3, ldx, n_src, aux_delta) + cc);
       }
-      const gfp wk = wp + (int64_t)g_begin * 8 * Ncols * 4;
+      const int ktw0 = MODE == MODE_DENSE ? g_begin : d0 * tpd + g_begin / ndir;
+      const gfp wk = wp + (int64_t)ktw0 * 8 * Ncols * 4;
       vb0 = ldg4(wk + bo0);
       if (NB > 1) vb1 = ldg4(wk + bo1);
       if (NB > 2) { vb2 = ldg4(wk + bo2); vb3 = ldg4(wk + bo3); }
@@ -493,22 +496,22 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(const GemmArgs g) {
       const int buf = (kt - g_begin) & 1;
       // prefetch: indices of tile kt+2, rows + weights of tile kt+1 (clamped at the last gather tile)
       const int ktn = kt + 1 < nkt_g ? kt + 1 : nkt_g - 1;
-      const int dn = ktn / tpd;
-      const int d2c = (kt + 2) / tpd;
-      const int d2 = d2c < ndir ? d2c : ndir - 1;
+      const int dn = ktn % ndir;
+      const int d2 = (kt + 2 < nkt_g ? kt + 2 : nkt_g - 1) % ndir;
       if (MODE == MODE_DENSE) {
         int cc = ktn * BK + c4 * 4;
         cc = cc < kclamp ? cc : kclamp;
         va0 = ldg4(dp0 + cc); va1 = ldg4(dp1 + cc); va2 = ldg4(dp2 + cc); va3 = ldg4(dp3 + cc);
       } else {
         ib0 = t0[d2]; ib1 = t1[d2]; ib2 = t2[d2]; ib3 = t3[d2];
-        const int cc = (ktn - dn * tpd) * BK + c4 * 4;
+        const int cc = (ktn / ndir) * BK + c4 * 4;
         va0 = ldg4(xp + src_off(ia0, ldx, n_src, aux_delta) + cc);
         va1 = ldg4(xp + src_off(ia1, ldx, n_src, aux_delta) + cc);
         va2 = ldg4(xp + src_off(ia2, ldx, n_src, aux_delta) + cc);
         va3 = ldg4(xp + src_off(ia3, ldx, n_src, aux_delta) + cc);
       }
-      const gfp wk = wp + (int64_t)ktn * 8 * Ncols * 4;
+      const int ktw = MODE == MODE_DENSE ? ktn : dn * tpd + ktn / ndir;
+      const gfp wk = wp + (int64_t)ktw * 8 * Ncols * 4;
       vb0 = ldg4(wk + bo0);
       if (NB > 1) vb1 = ldg4(wk + bo1);
       if (NB > 2) { vb2 = ldg4(wk + bo2); vb3 = ldg4(wk + bo3); }
@@ -614,13 +617,17 @@ __device__ __forceinline__ void split_bf16x4(const float4& v, uint2& hi, uint2& 
 
 template <int MODE, int WM, int WN, int MI, int NI>
 __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
+  // LDS carries only the A tile (hi and lo planes, [128][32+8] bf16 each, double buffered = 40 KB).
+  // The weight fragments go global(L2) -> registers directly in MFMA operand layout (the packed
+  // [k/8][n][8] planes give every lane one contiguous 16-B read): with B also staged through LDS the
+  // LDS pipe (writes at ~80 B/clk + reads) was ~85 % as busy as the matrix pipe and capped the kernel.
   constexpr int BN = WN * NI * 32;
-  constexpr int NBQ = BN >= 64 ? BN / 64 : 1;           // 16-B weight chunks per thread per (hi|lo) tile
   constexpr int A_BYTES = BM * 80;                      // one A plane (hi or lo)
-  constexpr int B_BYTES = 4 * BN * 16;                  // one B plane
-  constexpr int BUF_BYTES = 2 * A_BYTES + 2 * B_BYTES;
+  constexpr int BUF_BYTES = 2 * A_BYTES;
   static_assert(WM * MI * 32 == BM, "BM");
   extern __shared__ __attribute__((aligned(16))) char smem8[];
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef const u32x4 __attribute__((address_space(1)))* gqp;
 
   const int ntile = g.ntm * g.ntn;
   const int nblk = ntile * g.nsplit;
@@ -641,14 +648,12 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
 
   const gfp xp = (gfp)sgpr64((uint64_t)(MODE == MODE_DENSE ? g.A : g.x));
   const gfp tfp = (gfp)sgpr64((uint64_t)g.tf);
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  typedef const u32x4 __attribute__((address_space(1)))* gqp;
   const gqp w16 = (gqp)sgpr64((uint64_t)g.W16);
   const gip tab = (gip)sgpr64((uint64_t)g.nbr_ext);
   const int64_t ldx = (int64_t)sgpr64((uint64_t)(MODE == MODE_DENSE ? g.lda : g.ldx));
   const int64_t ldt = (int64_t)sgpr64((uint64_t)g.ldt), n_src = (int64_t)sgpr64((uint64_t)g.n_src);
   const int64_t Ncols = (int64_t)sgpr64((uint64_t)g.N);
-  const int64_t lo_off = (int64_t)sgpr64((uint64_t)(g.Kp / 8 * g.N));     // uint4 units: hi plane -> lo plane
+  const int64_t lo_off = (int64_t)sgpr64((uint64_t)(g.Kp / 8 * g.N));     // u32x4 units: hi plane -> lo plane
   const int64_t aux_delta = (int64_t)sgpr64((uint64_t)((g.aux - g.x) - g.n_src * g.ldx));
   const int ndir = g.ndir;
 
@@ -682,152 +687,149 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
   const gfp dp0 = xp + dr0 * ldx, dp1 = xp + dr1 * ldx, dp2 = xp + dr2 * ldx, dp3 = xp + dr3 * ldx;
   const int kclamp = (int)g.K - 4;
 
-  // weight chunk offsets (uint4 units inside one plane of one k-tile): chunk q = kgroup*BN + n
-  int64_t bo[NBQ];
-  const bool b_active = (BN >= 64) || threadIdx.x < 4 * BN;
+  // this lane's weight-fragment columns (clamped) -- B operand: lane (j = l31, h) holds W[k = 8(2c+h)..+7][n]
+  int64_t bcol[NI];
 #pragma unroll
-  for (int i = 0; i < NBQ; ++i) {
-    int q = threadIdx.x + 256 * i;
-    q = q < 4 * BN ? q : 4 * BN - 1;
-    int64_t nn = n0 + q % BN;
-    nn = nn < Ncols ? nn : Ncols - 1;
-    bo[i] = (int64_t)(q / BN) * Ncols + nn;
+  for (int j = 0; j < NI; ++j) {
+    int64_t nn = n0 + (wn * NI + j) * 32 + l31;
+    bcol[j] = (nn < Ncols ? nn : Ncols - 1) + (int64_t)h * Ncols;       // + kgroup h
   }
   char* const a_st = smem8 + (r0 * 80 + c4 * 8);
-  char* const b_st = smem8 + 2 * A_BYTES + threadIdx.x * 16;
   const char* const a_ld = smem8 + ((wm * MI * 32 + l31) * 80 + 16 * h);
-  const char* const b_ld = smem8 + 2 * A_BYTES + ((h * BN + wn * NI * 32 + l31) * 16);
 
-  float4 va0, va1, va2, va3;
-  u32x4 wh[NBQ], wl[NBQ];
+  struct BFrag { u32x4 h[2][NI], l[2][NI]; };          // [chunk][j]
+  struct RegSet { float4 a0, a1, a2, a3; };
+  struct IdxSet { uint32_t i0, i1, i2, i3; };
 
-  auto load_w = [&](int kt) {
-    const gqp wk = w16 + (int64_t)kt * 4 * Ncols;
+  auto load_bfrag = [&](int ktw, BFrag& F) {            // ktw = packed k-tile index (direction-major)
+    const gqp wk = w16 + (int64_t)ktw * 4 * Ncols;
 #pragma unroll
-    for (int i = 0; i < NBQ; ++i) { wh[i] = wk[bo[i]]; wl[i] = wk[lo_off + bo[i]]; }
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        F.h[c][j] = wk[(int64_t)(2 * c) * Ncols + bcol[j]];
+        F.l[c][j] = wk[lo_off + (int64_t)(2 * c) * Ncols + bcol[j]];
+      }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_a = [&](int buf, const RegSet& R) {
     char* a = a_st + buf * BUF_BYTES;
     uint2 hi, lo;
-    split_bf16x4(va0, hi, lo);
+    split_bf16x4(R.a0, hi, lo);
     *reinterpret_cast<uint2*>(a) = hi; *reinterpret_cast<uint2*>(a + A_BYTES) = lo;
-    split_bf16x4(va1, hi, lo);
+    split_bf16x4(R.a1, hi, lo);
     *reinterpret_cast<uint2*>(a + 32 * 80) = hi; *reinterpret_cast<uint2*>(a + 32 * 80 + A_BYTES) = lo;
-    split_bf16x4(va2, hi, lo);
+    split_bf16x4(R.a2, hi, lo);
     *reinterpret_cast<uint2*>(a + 64 * 80) = hi; *reinterpret_cast<uint2*>(a + 64 * 80 + A_BYTES) = lo;
-    split_bf16x4(va3, hi, lo);
+    split_bf16x4(R.a3, hi, lo);
     *reinterpret_cast<uint2*>(a + 96 * 80) = hi; *reinterpret_cast<uint2*>(a + 96 * 80 + A_BYTES) = lo;
-    if (b_active) {
-      char* b = b_st + buf * BUF_BYTES;
-#pragma unroll
-      for (int i = 0; i < NBQ; ++i) {
-        *reinterpret_cast<u32x4*>(b + i * 4096) = wh[i];
-        *reinterpret_cast<u32x4*>(b + i * 4096 + B_BYTES) = wl[i];
-      }
-    }
   };
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, const BFrag& F) {
     const char* a = a_ld + buf * BUF_BYTES;
-    const char* b = b_ld + buf * BUF_BYTES;
-    bf16x8_t ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+    bf16x8_t ah[2][MI], al[2][MI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      ah[0][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80);
-      al[0][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + A_BYTES);
-    }
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      bh[0][j] = *reinterpret_cast<const bf16x8_t*>(b + j * 32 * 16);
-      bl[0][j] = *reinterpret_cast<const bf16x8_t*>(b + j * 32 * 16 + B_BYTES);
-    }
+      for (int i = 0; i < MI; ++i) {
+        ah[c][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + 32 * c);
+        al[c][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + 32 * c + A_BYTES);
+      }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      if (c == 0) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          ah[1][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + 32);
-          al[1][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + 32 + A_BYTES);
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          bh[1][j] = *reinterpret_cast<const bf16x8_t*>(b + (2 * BN + j * 32) * 16);
-          bl[1][j] = *reinterpret_cast<const bf16x8_t*>(b + (2 * BN + j * 32) * 16 + B_BYTES);
-        }
-      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[c][i], bh[c][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c][i], bl[c][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c][i], bh[c][j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[c][i], __builtin_bit_cast(bf16x8_t, F.h[c][j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c][i], __builtin_bit_cast(bf16x8_t, F.l[c][j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c][i], __builtin_bit_cast(bf16x8_t, F.h[c][j]), acc[i][j], 0, 0, 0);
     }
   };
 
   // ------------------------------------------------------------ gather / dense tiles
+  // Iteration order: channel chunk OUTER, direction INNER (it -> dir = it % ndir, chunk = it / ndir):
+  // a row tile touches the same ~(tile + halo) source rows 7 (27) times back to back (L1/L2 hits).
+  // Pipeline: indices two tiles ahead, A rows + weight fragments one tile ahead (issued before the
+  // MFMA block and pinned there); the loop is unrolled by two over alternating fragment / index
+  // register sets so that nothing is copied (a copy would wait for its load).
   if (g_begin < g_end) {
-    int32_t ia0 = 0, ia1 = 0, ia2 = 0, ia3 = 0, ib0 = 0, ib1 = 0, ib2 = 0, ib3 = 0;
-    if (MODE == MODE_DENSE) {
-      int cc = g_begin * BK + c4 * 4;
-      cc = cc < kclamp ? cc : kclamp;
-      va0 = ldg4(dp0 + cc); va1 = ldg4(dp1 + cc); va2 = ldg4(dp2 + cc); va3 = ldg4(dp3 + cc);
-    } else {
-      const int d0 = g_begin / tpd;
-      const int d1c = (g_begin + 1) / tpd;
-      const int d1 = d1c < ndir ? d1c : ndir - 1;
-      ia0 = t0[d0]; ia1 = t1[d0]; ia2 = t2[d0]; ia3 = t3[d0];
-      ib0 = t0[d1]; ib1 = t1[d1]; ib2 = t2[d1]; ib3 = t3[d1];
-      const int cc = (g_begin - d0 * tpd) * BK + c4 * 4;
-      va0 = ldg4(xp + src_off(ia0, ldx, n_src, aux_delta) + cc);
-      va1 = ldg4(xp + src_off(ia1, ldx, n_src, aux_delta) + cc);
-      va2 = ldg4(xp + src_off(ia2, ldx, n_src, aux_delta) + cc);
-      va3 = ldg4(xp + src_off(ia3, ldx, n_src, aux_delta) + cc);
-    }
-    load_w(g_begin);
-    store_tiles(0);
-    ia0 = ib0; ia1 = ib1; ia2 = ib2; ia3 = ib3;
-    __syncthreads();
-
-    for (int kt = g_begin; kt < g_end; ++kt) {
-      const int buf = (kt - g_begin) & 1;
-      const int ktn = kt + 1 < nkt_g ? kt + 1 : nkt_g - 1;
+    RegSet R;
+    IdxSet I0 = {0, 0, 0, 0}, I1 = {0, 0, 0, 0};
+    BFrag F0, F1;
+    auto clampg = [&](int it) { return it < nkt_g ? it : nkt_g - 1; };
+    auto ktw_of = [&](int it) {
+      const int itc = clampg(it);
+      return MODE == MODE_DENSE ? itc : (itc % ndir) * tpd + itc / ndir;
+    };
+    auto load_idx = [&](int it, IdxSet& I) {
+      if (MODE == MODE_DENSE) return;
+      const int dc = clampg(it) % ndir;
+      I.i0 = (uint32_t)t0[dc]; I.i1 = (uint32_t)t1[dc]; I.i2 = (uint32_t)t2[dc]; I.i3 = (uint32_t)t3[dc];
+    };
+    auto load_rows = [&](int it, const IdxSet& I) {
+      const int itc = clampg(it);
       if (MODE == MODE_DENSE) {
-        int cc = ktn * BK + c4 * 4;
+        int cc = itc * BK + c4 * 4;
         cc = cc < kclamp ? cc : kclamp;
-        va0 = ldg4(dp0 + cc); va1 = ldg4(dp1 + cc); va2 = ldg4(dp2 + cc); va3 = ldg4(dp3 + cc);
+        R.a0 = ldg4(dp0 + cc); R.a1 = ldg4(dp1 + cc); R.a2 = ldg4(dp2 + cc); R.a3 = ldg4(dp3 + cc);
       } else {
-        const int dn = ktn / tpd;
-        const int d2c = (kt + 2) / tpd;
-        const int d2 = d2c < ndir ? d2c : ndir - 1;
-        ib0 = t0[d2]; ib1 = t1[d2]; ib2 = t2[d2]; ib3 = t3[d2];
-        const int cc = (ktn - dn * tpd) * BK + c4 * 4;
-        va0 = ldg4(xp + src_off(ia0, ldx, n_src, aux_delta) + cc);
-        va1 = ldg4(xp + src_off(ia1, ldx, n_src, aux_delta) + cc);
-        va2 = ldg4(xp + src_off(ia2, ldx, n_src, aux_delta) + cc);
-        va3 = ldg4(xp + src_off(ia3, ldx, n_src, aux_delta) + cc);
+        const int cc = (itc / ndir) * BK + c4 * 4;
+        R.a0 = ldg4(xp + src_off(I.i0, ldx, n_src, aux_delta) + cc);
+        R.a1 = ldg4(xp + src_off(I.i1, ldx, n_src, aux_delta) + cc);
+        R.a2 = ldg4(xp + src_off(I.i2, ldx, n_src, aux_delta) + cc);
+        R.a3 = ldg4(xp + src_off(I.i3, ldx, n_src, aux_delta) + cc);
       }
-      load_w(ktn);
-      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above the MFMA block (see gemm_fast_kernel)
-      compute(buf);
+    };
+    // one pipeline step: tile `it` is computed with Fcur; Iuse = indices of tile it+1
+    auto step = [&](int it, int buf, const IdxSet& Iuse, IdxSet& Iload, const BFrag& Fcur, BFrag& Fnext) {
+      load_idx(it + 2, Iload);
+      __builtin_amdgcn_sched_barrier(0);      // index loads stay OLDER than the row loads (counted vmcnt)
+      load_rows(it + 1, Iuse);
+      load_bfrag(ktw_of(it + 1), Fnext);
+      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above the MFMA block
+      compute(buf, Fcur);
       __builtin_amdgcn_sched_barrier(0);
-      store_tiles(buf ^ 1);
-      ia0 = ib0; ia1 = ib1; ia2 = ib2; ia3 = ib3;
+      store_a(buf ^ 1, R);                    // A rows of tile it+1 -> LDS
       __syncthreads();
+    };
+
+    load_idx(g_begin, I0);
+    load_idx(g_begin + 1, I1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(g_begin, I0);
+    load_bfrag(ktw_of(g_begin), F0);
+    __builtin_amdgcn_sched_barrier(0);
+    store_a(0, R);
+    __syncthreads();
+    int it = g_begin;
+    for (; it + 1 < g_end; it += 2) {
+      step(it, 0, I1, I0, F0, F1);
+      step(it + 1, 1, I0, I1, F1, F0);
     }
+    if (it < g_end) step(it, 0, I1, I0, F0, F1);
+    __syncthreads();
   }
 
   // ------------------------------------------------------------ node-type slab tiles
   for (int kt = t_begin; kt < kt_end; ++kt) {
     const int cc = (kt - nkt_g) * BK + c4 * 4;
-    va0 = ldg4(tfp + m_0 * ldt + cc);
-    va1 = ldg4(tfp + m_1 * ldt + cc);
-    va2 = ldg4(tfp + m_2 * ldt + cc);
-    va3 = ldg4(tfp + m_3 * ldt + cc);
-    load_w(kt);
-    store_tiles(0);
+    RegSet R;
+    BFrag F;
+    R.a0 = ldg4(tfp + m_0 * ldt + cc);
+    R.a1 = ldg4(tfp + m_1 * ldt + cc);
+    R.a2 = ldg4(tfp + m_2 * ldt + cc);
+    R.a3 = ldg4(tfp + m_3 * ldt + cc);
+    load_bfrag(kt, F);
+    store_a(0, R);
     __syncthreads();
-    compute(0);
+    compute(0, F);
     __syncthreads();
   }
 
@@ -966,7 +968,7 @@ static int launch_fast_cfg(GemmArgs& g, hipStream_t st) {
 template <int MODE, int WM, int WN, int MI, int NI>
 static int launch_bf16x3_cfg(GemmArgs& g, hipStream_t st) {
   constexpr int BN = WN * NI * 32;
-  constexpr size_t lds = 2 * (2 * BM * 80 + 2 * 4 * BN * 16);
+  constexpr size_t lds = 2 * (2 * BM * 80);
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<MODE, WM, WN, MI, NI>),

@@ -188,6 +188,14 @@ class DualOctree:
             self._tf[key] = tf
         return self._tf[key]
 
+    def pad_rows(self, d):
+        """int32 [N_d]: position of graph row r inside the node_mask-long padded array
+        (graph_vae.py:214-221: `pad[node_mask] = reg`)."""
+        key = ('pad', d)
+        if key not in self._maps:
+            self._maps[key] = torch.nonzero(self.graph[d]['node_mask']).reshape(-1).to(torch.int32)
+        return self._maps[key]
+
     def pool_maps(self, d):
         """Row maps for GraphDownsample d -> d-1 (modules.py:409-423).
 

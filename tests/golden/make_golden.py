@@ -340,7 +340,38 @@ def g_sample_loop():
     save('g_sample_loop', out)
 
 
+# ---------------------------------------------------------------- G8
+VAE_CFG = dict(depth=6, channel_in=4, nout=4, full_depth=2, depth_stop=4, depth_out=6, use_checkpoint=False,
+               resblk_type='basic', bottleneck=4, resblk_num=2, code_channel=16, embed_dim=3)
+
+
+def g_vae():
+    from models.networks.dualoctree_networks.graph_vae import GraphVAE
+    split, oc, doc = tiny_doctree()
+    sl = C.random_split_large(int(oc.nnum[4]), 11, p=0.3)
+    oc_l = split2octree_large(oc, sl, 4)
+    doc_l = RD.DualOctree(oc_l)
+    doc_l.post_processing_for_docnn()
+    vae = GraphVAE(**VAE_CFG).eval()
+    ks = load_filled(vae)
+    N4 = doc_l.graph[4]['node_type'].numel()
+    code = C.rand_input('vae_code', N4, 3)
+    out = vae.decode_code(code, doc_l, update_octree=False)
+    rec = {'split_small': split, 'split_large': sl, 'keys': ks, 'cfg': VAE_CFG,
+           'logits': {d: v.clone() for d, v in out['logits'].items()},
+           'reg_voxs': {d: v.clone() for d, v in out['reg_voxs'].items()}}
+    # update_octree=True: structure depends on argmax decisions; record them with their margins
+    import copy
+    doc_in = RD.DualOctree(copy.deepcopy(oc_l))
+    doc_in.post_processing_for_docnn()
+    out2 = vae.decode_code(code, doc_in, update_octree=True)
+    rec['grow'] = {'logits': {d: v.clone() for d, v in out2['logits'].items()},
+                   'nnum': out2['octree_out'].nnum.clone(), 'nnum_nempty': out2['octree_out'].nnum_nempty.clone(),
+                   'reg_shapes': {d: tuple(v.shape) for d, v in out2['reg_voxs'].items()}}
+    save('g_vae', rec)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['octree_graph', 'modules', 'dense', 'unet', 'sample_loop']
+    which = sys.argv[1:] or ['octree_graph', 'modules', 'dense', 'unet', 'sample_loop', 'vae']
     for w in which:
         globals()['g_' + w]()

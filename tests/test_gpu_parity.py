@@ -364,3 +364,30 @@ def union_cfg(num_classes=None):
     if num_classes is not None:
         cfg['num_classes'] = num_classes
     return cfg
+
+
+def test_vae_decoder(golden):
+    """GraphVAE.decode_code on libofx: fixed octree vs golden; growth path (argmax -> split -> grow ->
+    rebuilt dual graph on device) vs golden counts + logits."""
+    from octfusion_amd.graph_vae import GraphVAE
+    from octfusion_amd.octree import split2octree_large
+    from octfusion_amd.dual_octree import DualOctree
+    G = golden('g_vae')
+    oc, doc = tiny(G['split_small'])
+    oc_l = split2octree_large(oc, G['split_large'].to(dev()), 4)
+    doc_l = DualOctree(oc_l)
+    vae = load(GraphVAE(**G['cfg']), G['keys'])
+    code = C.rand_input('vae_code', doc_l.csr(4)[2], 3).to(dev())
+    out = vae.decode_code(code, doc_l, update_octree=False)
+    for d in (4, 5, 6):
+        close(out['logits'][d], G['logits'][d], 1e-3)
+        close(out['reg_voxs'][d], G['reg_voxs'][d], 1e-3)
+    out2 = vae.decode_code(code, DualOctree(split2octree_large(oc, G['split_large'].to(dev()), 4)), update_octree=True)
+    # decisions are argmax over 2 logits: identical unless a margin is below the fp tolerance
+    for d in (4, 5, 6):
+        ref = G['grow']['logits'][d]
+        margin = (ref[:, 0] - ref[:, 1]).abs().min()
+        if d == 4 or float(margin) > 1e-3 * float(ref.abs().max()):
+            close(out2['logits'][d], ref, 1e-3)
+        assert tuple(out2['reg_voxs'][d].shape) == G['grow']['reg_shapes'][d]
+    assert torch.equal(out2['octree_out'].nnum[:7], G['grow']['nnum'])

@@ -237,3 +237,27 @@ def test_sample_loop(golden, name, unet_type, df_type):
     y = OS.sample_loop(fake_net(r['shape']), r['shape'], r['B'], r['steps'], unet_type, df_type,
                        r.get('trunc', 0.0))
     torch.testing.assert_close(y, r['out'], **TOL)
+
+
+def test_vae_decoder(golden):
+    from oracle import vae as OV
+    G = golden('g_vae')
+    oc, doc = tiny(G['split_small'])
+    oc_l = OS.split2octree_large(oc, G['split_large'], 4)
+    doc_l = OD.OracleDualOctree(oc_l)
+    doc_l.post_processing_for_docnn()
+    sd = C.fill_state_dict(G['keys'])
+    code = C.rand_input('vae_code', doc_l.graph[4]['node_type'].numel(), 3)
+    logits, regs, _ = OV.decode_code(sd, G['cfg'], code, doc_l, update_octree=False)
+    for d in (4, 5, 6):
+        torch.testing.assert_close(logits[d], G['logits'][d], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(regs[d], G['reg_voxs'][d], rtol=2e-4, atol=2e-5)
+    # growth path: same argmax decisions -> same octree (the logits at every depth are pinned too)
+    import copy
+    doc_in = OD.OracleDualOctree(copy.deepcopy(oc_l))
+    doc_in.post_processing_for_docnn()
+    logits2, regs2, oct2 = OV.decode_code(sd, G['cfg'], code, doc_in, update_octree=True)
+    assert torch.equal(oct2.nnum, G['grow']['nnum']) and torch.equal(oct2.nnum_nempty, G['grow']['nnum_nempty'])
+    for d in (4, 5, 6):
+        torch.testing.assert_close(logits2[d], G['grow']['logits'][d], rtol=2e-4, atol=2e-5)
+        assert tuple(regs2[d].shape) == G['grow']['reg_shapes'][d]

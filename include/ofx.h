@@ -258,8 +258,11 @@ int ofx_act(const float* x, float* y, int64_t n, int act, void* stream);
 int ofx_timestep_embedding(const float* t, int batch_size, int dim, float max_period,
                            float* out, void* stream);
 /* DDIM eps-branch update (octfusion_model_union.py:345-350), coef on device:
- * coef = {alpha, sigma, alpha_next, sigma_next}; x updated in place. */
-int ofx_ddim_eps_update(float* x, const float* eps, const float* coef, int64_t n, void* stream);
+ * coef = {alpha, sigma, alpha_next, sigma_next}; x updated in place; x0_out (optional)
+ * receives x_start = (x - eps*sigma)/max(alpha,1e-8), which the reference hands to the next
+ * step as x_self_cond. */
+int ofx_ddim_eps_update(float* x, const float* eps, const float* coef, float* x0_out, int64_t n,
+                        void* stream);
 /* DDIM x0-branch update (:326-344): x = mean + sqrt(var) * noise with
  * coef = {alpha, c, alpha_next, sqrt(sigma_next^2 * c) or 0 when truncated}. */
 int ofx_ddim_x0_update(float* x, const float* x0, const float* noise, const float* coef,

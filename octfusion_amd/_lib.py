@@ -73,7 +73,7 @@ _SIGS = {
     'ofx_rows_copy': (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_p], True),
     'ofx_act': (c_i, [c_p, c_p, c_l, c_i, c_p], True),
     'ofx_timestep_embedding': (c_i, [c_p, c_i, c_i, c_f, c_p, c_p], True),
-    'ofx_ddim_eps_update': (c_i, [c_p, c_p, c_p, c_l, c_p], True),
+    'ofx_ddim_eps_update': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p], True),
     'ofx_ddim_x0_update': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p], True),
 }
 

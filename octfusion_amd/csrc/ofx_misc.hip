@@ -94,18 +94,20 @@ extern "C" int ofx_timestep_embedding(const float* t, int batch_size, int dim, f
 }
 
 __global__ void ddim_eps_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ coef,
-                                int64_t n) {
+                                float* __restrict__ x0_out, int64_t n) {
   const float alpha = coef[0], sigma = coef[1], alpha_n = coef[2], sigma_n = coef[3];
   const float a = fmaxf(alpha, 1e-8f);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float e = eps[i];
     const float x0 = (x[i] - e * sigma) / a;
+    if (x0_out) x0_out[i] = x0;
     x[i] = x0 * alpha_n + e * sigma_n;
   }
 }
-extern "C" int ofx_ddim_eps_update(float* x, const float* eps, const float* coef, int64_t n, void* stream) {
+extern "C" int ofx_ddim_eps_update(float* x, const float* eps, const float* coef, float* x0_out, int64_t n,
+                                   void* stream) {
   if (n < 0 || !coef || (n > 0 && (!x || !eps))) return OFX_EINVAL;
-  if (n > 0) ddim_eps_kernel<<<ofx_grid(n, 256), 256, 0, ofx_stream(stream)>>>(x, eps, coef, n);
+  if (n > 0) ddim_eps_kernel<<<ofx_grid(n, 256), 256, 0, ofx_stream(stream)>>>(x, eps, coef, x0_out, n);
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }

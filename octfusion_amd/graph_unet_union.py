@@ -41,6 +41,8 @@ class UNet3DModel(nn.Module):
             if kind == stage_flag:
                 break
 
+    wants_self_cond = False      # only the lr stage consumes x_self_cond, and it runs the x0 branch
+
     def forward(self, unet_type=None, **input_data):
         if unet_type == 'lr':
             return self.unet_lr(**input_data)

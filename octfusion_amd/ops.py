@@ -334,10 +334,10 @@ def voxel2octree_cf(vox, depth, out=None):
     return out
 
 
-def ddim_eps_update(x, eps, coef):
-    _chk(x), _chk(eps), _chk(coef)
+def ddim_eps_update(x, eps, coef, x0_out=None):
+    _chk(x), _chk(eps), _chk(coef), _chk(x0_out)
     assert x.is_contiguous() and eps.is_contiguous()
-    call('ofx_ddim_eps_update', ptr(x), ptr(eps), ptr(coef), x.numel(), stream())
+    call('ofx_ddim_eps_update', ptr(x), ptr(eps), ptr(coef), ptr(x0_out), x.numel(), stream())
     return x
 
 

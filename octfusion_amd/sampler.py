@@ -72,7 +72,12 @@ def sample_loop(net, shape, batch_size, ddim_steps, unet_type, df_type, device, 
                 noise = torch.randn_like(x) if step_noise is None else step_noise[i].to(device)
             ops.ddim_x0_update(x, out, noise, coef)
         elif df_type == 'eps':
-            ops.ddim_eps_update(x, out, eps_coef(t, t_next).to(device))
+            # the reference also keeps x_start = (x - eps*sigma)/alpha and passes it on as x_self_cond
+            # (octfusion_model_union.py:349, :320); the hr / feature nets ignore it, so it is only
+            # materialised for nets that declare they want it.
+            x0_out = torch.empty_like(x) if getattr(net, 'wants_self_cond', True) else None
+            ops.ddim_eps_update(x, out, eps_coef(t, t_next).to(device), x0_out)
+            x_start = x0_out
         else:
             raise ValueError(df_type)
     return x

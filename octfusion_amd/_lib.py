@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libofx.so')
+LIB_PATH = os.environ.get('OFX_LIB', os.path.join(_HERE, 'libofx.so'))   # OFX_LIB: experiment builds
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int

@@ -187,7 +187,10 @@ int ofx_gemm_f32(const float* A, int64_t lda, const int32_t* a_rows, int64_t M, 
  * nbr = ofx_graph_primary table (generic path: any cin).  nbr_ext / multi_seg / aux
  * (scratch of (n_multi+1)*cin floats) enable the branch-free fast path when
  * cin % 32 == 0: a pre-pass averages the few multi-neighbour segments into aux, the
- * main kernel then gathers exactly one row per (row,dir).  ws: split-K workspace. */
+ * main kernel then gathers exactly one row per (row,dir).  ws: split-K workspace.
+ * stats (optional, needs batch_id): the epilogue also accumulates the GroupNorm statistics
+ * of the OUTPUT, stats[(b*stats_ld + n)*2 + {0,1}] += (v, v^2) in fp64 (caller zeroes it),
+ * in the layout ofx_gn_finalize reads -- the consuming norm then skips ofx_gn_stats. */
 int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes,
                       const int32_t* nbr, const int32_t* seg_ptr, const int32_t* col,
                       const int32_t* nbr_ext, const int32_t* multi_seg, int64_t n_multi, float* aux,
@@ -195,6 +198,7 @@ int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes,
                       const float* Wp, int64_t Kp, int cout, const float* bias,
                       const float* emb, int64_t lde, const int32_t* batch_id,
                       const float* res, int64_t ldr, float* out, int64_t ldc,
+                      double* stats /* optional */, int64_t stats_ld,
                       void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- dense grids

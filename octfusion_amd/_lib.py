@@ -56,7 +56,7 @@ _SIGS = {
     'ofx_pack_weights': (c_i, [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_p, c_l, c_p], True),
     'ofx_gemm_f32': (c_i, [c_p, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_sz, c_p], True),
     'ofx_graphconv_fwd': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l,
-                                c_i, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_sz, c_p], True),
+                                c_i, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_sz, c_p], True),
     'ofx_graph_multi_flag': (c_i, [c_p, c_l, c_p, c_p], True),
     'ofx_graph_primary_ext': (c_i, [c_p, c_p, c_l, c_p, c_p, c_p, c_p], True),
     'ofx_graph_primary': (c_i, [c_p, c_p, c_l, c_p, c_p], True),

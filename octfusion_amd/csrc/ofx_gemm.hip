@@ -49,6 +49,7 @@ struct GemmArgs {
   const float* emb; int64_t lde; const int32_t* bid;
   const float* res; int64_t ldr;
   float* out; int64_t ldc; const int32_t* out_rows;
+  double* stats; int64_t stats_ld;   // optional fused GroupNorm statistics: stats[(b*stats_ld + n)*2 + {0,1}] += (v, v*v)
   int ntm, ntn, nsplit, kt_per_split;
   float* ws;               // split-K partials [nsplit][M][N]
 };
@@ -117,6 +118,67 @@ __device__ __forceinline__ void load_b_tile(const GemmArgs& g, int64_t n0, int64
     const int kql = idx / BN, n = idx % BN;
     const int64_t nn = n0 + n;
     vb[i] = (nn < g.N) ? *reinterpret_cast<const float4*>(g.Wp + (((k0 >> 2) + kql) * g.N + nn) * 4) : f4zero();
+  }
+}
+
+
+// Epilogue shared by the MFMA kernels.  C/D layout of the 32x32 MFMA: col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  out = acc + bias + emb[bid[m]] + res[m]; optionally also
+// accumulates the per-(batch element, channel) sum / sum of squares of the stored values in fp64
+// (hardware global_atomic_add_f64), so the DualOctreeGroupNorm that consumes this tensor needs no
+// statistics pass of its own (reference modules.py:299-311 makes three scatter passes).
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, f32x16 (&acc)[MI][NI], int64_t m0, int64_t n0, int wm,
+                                               int wn, int l31, int h, int split) {
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int64_t n = n0 + (wn * NI + j) * 32 + l31;
+    if (n >= g.N) continue;
+    if (g.nsplit > 1) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < g.M) g.ws[((int64_t)split * g.M + m) * g.N + n] = acc[i][j][r];
+        }
+      continue;
+    }
+    const float bv = g.bias ? g.bias[n] : 0.f;
+    int sb = -1;                 // statistics run: batch id, sum, sum of squares
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        int b = 0;
+        if (g.emb || g.stats) b = g.bid[m];
+        if (g.emb) v += g.emb[(int64_t)b * g.lde + n];
+        if (g.res) v += g.res[m * g.ldr + n];
+        if (g.stats) {
+          if (b != sb) {
+            if (sb >= 0) {
+              double* o = g.stats + ((int64_t)sb * g.stats_ld + n) * 2;
+              unsafeAtomicAdd(o, (double)ssum);
+              unsafeAtomicAdd(o + 1, (double)ssq);
+            }
+            sb = b; ssum = 0.f; ssq = 0.f;
+          }
+          ssum += v; ssq += v * v;
+        }
+        int64_t om = m;
+        if (g.out_rows) { om = g.out_rows[m]; if (om < 0) continue; }
+        g.out[om * g.ldc + n] = v;
+      }
+    }
+    if (g.stats && sb >= 0) {
+      double* o = g.stats + ((int64_t)sb * g.stats_ld + n) * 2;
+      unsafeAtomicAdd(o, (double)ssum);
+      unsafeAtomicAdd(o + 1, (double)ssq);
+    }
   }
 }
 
@@ -265,35 +327,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
     __syncthreads();
   }
 
-  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int64_t n = n0 + (wn * NI + j) * 32 + l31;
-      if (n >= g.N) continue;
-      if (g.nsplit > 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (m < g.M) g.ws[((int64_t)split * g.M + m) * g.N + n] = acc[i][j][r];
-        }
-        continue;
-      }
-      const float bv = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= g.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (g.emb) v += g.emb[(int64_t)g.bid[m] * g.lde + n];
-        if (g.res) v += g.res[m * g.ldr + n];
-        int64_t om = m;
-        if (g.out_rows) { om = g.out_rows[m]; if (om < 0) continue; }
-        g.out[om * g.ldc + n] = v;
-      }
-    }
-  }
+  epilogue_store<WM, WN, MI, NI>(g, acc, m0, n0, wm, wn, l31, h, split);
 }
 
 
@@ -557,34 +591,7 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(const GemmArgs g) {
     __syncthreads();
   }
 
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int64_t n = n0 + (wn * NI + j) * 32 + l31;
-      if (n >= g.N) continue;
-      if (g.nsplit > 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (m < g.M) g.ws[((int64_t)split * g.M + m) * g.N + n] = acc[i][j][r];
-        }
-        continue;
-      }
-      const float bv = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= g.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (g.emb) v += g.emb[(int64_t)g.bid[m] * g.lde + n];
-        if (g.res) v += g.res[m * g.ldr + n];
-        int64_t om = m;
-        if (g.out_rows) { om = g.out_rows[m]; if (om < 0) continue; }
-        g.out[om * g.ldc + n] = v;
-      }
-    }
-  }
+  epilogue_store<WM, WN, MI, NI>(g, acc, m0, n0, wm, wn, l31, h, split);
 }
 
 
@@ -833,34 +840,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
     __syncthreads();
   }
 
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int64_t n = n0 + (wn * NI + j) * 32 + l31;
-      if (n >= g.N) continue;
-      if (g.nsplit > 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (m < g.M) g.ws[((int64_t)split * g.M + m) * g.N + n] = acc[i][j][r];
-        }
-        continue;
-      }
-      const float bv = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= g.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (g.emb) v += g.emb[(int64_t)g.bid[m] * g.lde + n];
-        if (g.res) v += g.res[m * g.ldr + n];
-        int64_t om = m;
-        if (g.out_rows) { om = g.out_rows[m]; if (om < 0) continue; }
-        g.out[om * g.ldc + n] = v;
-      }
-    }
-  }
+  epilogue_store<WM, WN, MI, NI>(g, acc, m0, n0, wm, wn, l31, h, split);
 }
 
 // split the fp32-packed weights [k/4][n][4] into bf16 hi | lo planes, each [k/8][n][8]
@@ -1145,7 +1125,8 @@ extern "C" int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n
                                  const int32_t* multi_seg, int64_t n_multi, float* aux, const float* type_frac,
                                  int64_t ldt, int nt_pad, const float* Wp, int64_t Kp, int cout, const float* bias,
                                  const float* emb, int64_t lde, const int32_t* batch_id, const float* res, int64_t ldr,
-                                 float* out, int64_t ldc, void* ws, size_t ws_bytes, void* stream) {
+                                 float* out, int64_t ldc, double* stats, int64_t stats_ld, void* ws, size_t ws_bytes,
+                                 void* stream) {
   GemmArgs g = {};
   int rc = gather_common(g, x, ldx, cin, 7, n_nodes, nbr, seg_ptr, col, Wp, Kp, cout, bias, emb, lde, batch_id, res,
                          ldr, out, ldc);
@@ -1154,6 +1135,11 @@ extern "C" int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n
   if (nt_pad < 0 || (nt_pad & 31) || Kp != g.Kf + nt_pad) return OFX_EINVAL;
   if (nt_pad > 0 && (!type_frac || ldt < nt_pad || (ldt & 3) || ((uintptr_t)type_frac & 15))) return OFX_EINVAL;
   g.tf = type_frac; g.ldt = ldt;
+  if (stats) {
+    if (!batch_id || stats_ld < cout) return OFX_EINVAL;
+    g.stats = stats; g.stats_ld = stats_ld; g.bid = batch_id;
+    ws = nullptr;                              // fused statistics need the single-pass epilogue (no split-K)
+  }
   hipStream_t st = ofx_stream(stream);
   if (g.fast && nbr_ext && aux && n_nodes > 0 && (((uintptr_t)aux & 15) == 0)) {
     if (n_multi < 0 || (n_multi > 0 && !multi_seg)) return OFX_EINVAL;

@@ -98,6 +98,7 @@ class UNet3DModel(nn.Module):
         self.end_norm = graphnormalization(ch)
         self.end = nn.SiLU()
         self.out = GraphConv(ch, out_channels, et, deg, input_depth - 1)
+        self.out.emit_stats = False
         for p in self.out.parameters():          # zero_module (graph_unet_hr.py:209)
             p.detach().zero_()
 
@@ -132,12 +133,12 @@ class UNet3DModel(nn.Module):
         if unet_lr is not None:
             h = self.middle_block1(h, emb, doctree, d, emb_act=emb_act)
             h_lr = unet_lr.forward_as_middle(h, doctree, timesteps, label, context)
-            h = torch.cat([h, h_lr], dim=1)
+            h = ops.cat_channels(h, h_lr)
             h = self.middle_block2(h, emb, doctree, d, emb_act=emb_act)
 
         for (kind, dd, _), module in zip(self._dec, self.output_blocks):
             if kind == 'res':
-                h = torch.cat([h, hs.pop()], dim=1)
+                h = ops.cat_channels(h, hs.pop())
                 h = module(h, emb, doctree, dd, emb_act=emb_act)
             else:
                 h = module(h, doctree, dd)

@@ -48,6 +48,7 @@ class GraphConv(nn.Module):
             self.bias = nn.Parameter(torch.empty(out_channels))
         self.reset_parameters()
         self._pw = ops.PackedWeight()
+        self.emit_stats = True
 
     def reset_parameters(self):
         fan_in = self.avg_degree * self.in_channels
@@ -66,9 +67,18 @@ class GraphConv(nn.Module):
         seg_ptr, col, N, E = doctree.csr(d)
         assert x.shape[0] == N, 'x has %d rows, graph depth %d has %d nodes' % (x.shape[0], d, N)
         tf = doctree.type_frac(d, nt) if nt else None
-        return ops.graphconv(x, doctree.nbr(d), seg_ptr, col, pw, self.in_channels, tf,
-                             self.bias if self.use_bias else None, emb,
-                             doctree.batch_id32(d) if emb is not None else None, res, out, ext=doctree.ext(d))
+        # large outputs feed a DualOctreeGroupNorm next: let the epilogue accumulate its statistics
+        stats = None
+        if self.emit_stats and self.in_channels % 32 == 0 and N * self.out_channels >= (1 << 20) \
+                and self.out_channels % 4 == 0:
+            stats = torch.zeros(doctree.batch_size * self.out_channels * 2, dtype=torch.float64, device=x.device)
+        y = ops.graphconv(x, doctree.nbr(d), seg_ptr, col, pw, self.in_channels, tf,
+                          self.bias if self.use_bias else None, emb,
+                          doctree.batch_id32(d) if (emb is not None or stats is not None) else None, res, out,
+                          ext=doctree.ext(d), stats=stats)
+        if stats is not None:
+            setattr(y, ops.STATS_ATTR, stats)
+        return y
 
     def extra_repr(self):
         return 'channel_in={}, channel_out={}, n_edge_type={}, avg_degree={}, n_node_type={}'.format(
@@ -91,8 +101,12 @@ class DualOctreeGroupNorm(nn.Module):
     @torch.no_grad()
     def forward(self, data, doctree, depth, act=None, out=None):
         assert doctree.batch_id32(depth).shape[0] == data.shape[0]
-        return ops.group_norm(data, doctree.batch_id32(depth), doctree.count(depth), doctree.batch_size,
-                              self.weights, self.bias, self.group, self.eps, act, out)
+        stats = ops.get_stats(data)
+        y = ops.group_norm(data, doctree.batch_id32(depth), doctree.count(depth), doctree.batch_size,
+                           self.weights, self.bias, self.group, self.eps, act, out, stats=stats)
+        if out is data and stats is not None:
+            delattr(data, ops.STATS_ATTR)          # overwritten in place: the sums no longer describe it
+        return y
 
     def extra_repr(self):
         return 'in_channels={}, group={}, nempty={}'.format(self.in_channels, self.group, self.nempty)

@@ -137,8 +137,10 @@ def zero_row(device, n=4096):
 
 
 def graphconv(x, nbr, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None, batch_id=None,
-              res=None, out=None, ext=None):
-    """ext = (nbr_ext, multi_seg, n_multi) enables the branch-free fast path (cin % 32 == 0)."""
+              res=None, out=None, ext=None, stats=None):
+    """ext = (nbr_ext, multi_seg, n_multi) enables the branch-free fast path (cin % 32 == 0).
+    stats (fp64 [B, Cout, 2], zeroed, needs batch_id): the epilogue also accumulates the GroupNorm
+    statistics of the output."""
     """Fused dual-octree graph convolution (gather -> segment mean -> MFMA contraction)."""
     x, ldx = _row_major(x)
     N = x.shape[0]
@@ -156,10 +158,12 @@ def graphconv(x, nbr, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None
     lde = ldr = 0
     if emb is not None:
         emb, lde = _row_major(emb)
+    if emb is not None or stats is not None:
         _chk(batch_id, torch.int32)
     if res is not None:
         res, ldr = _row_major(res)
     _chk(bias)
+    _chk(stats, torch.float64)
     prof = GRAPHCONV_PROFILE
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -173,8 +177,9 @@ def graphconv(x, nbr, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None
         aux = torch.empty((n_multi + 1) * ldx, dtype=torch.float32, device=x.device)
     call('ofx_graphconv_fwd', ptr(x), ldx, cin, N, ptr(nbr), ptr(seg_ptr), ptr(col), ptr(nbr_ext), ptr(multi_seg),
          n_multi, ptr(aux), ptr(type_frac), ldt, nt_pad,
-         ptr(pw.t), pw.Kp, pw.N, ptr(bias), ptr(emb), lde, ptr(batch_id) if emb is not None else None,
-         ptr(res), ldr, ptr(out), ldc, ptr(ws), ws.numel(), stream())
+         ptr(pw.t), pw.Kp, pw.N, ptr(bias), ptr(emb), lde,
+         ptr(batch_id) if (emb is not None or stats is not None) else None,
+         ptr(res), ldr, ptr(out), ldc, ptr(stats), pw.N, ptr(ws), ws.numel(), stream())
     if prof is not None:
         e1.record()
         E = col.numel()
@@ -263,17 +268,23 @@ def gather_mean(x, seg_ptr, col):
 
 
 def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, act=None, out=None,
-               count_eps=None):
-    """DualOctreeGroupNorm (+ optional fused activation).  count_eps=0 gives torch.nn.GroupNorm."""
+               count_eps=None, stats=None):
+    """DualOctreeGroupNorm (+ optional fused activation).  count_eps=0 gives torch.nn.GroupNorm.
+    stats: fp64 [B, C, 2] sums already produced by the epilogue of the kernel that wrote x."""
     if count_eps is None:
         count_eps = eps
     x, ldx = _row_major(x)
     n, C = x.shape
     dev = x.device
-    sums = torch.empty(batch_size * C * 2, dtype=torch.float64, device=dev)
     mean = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
     rstd = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
-    call('ofx_gn_stats', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
+    if stats is not None:
+        _chk(stats, torch.float64)
+        assert stats.numel() == batch_size * C * 2
+        sums = stats
+    else:
+        sums = torch.empty(batch_size * C * 2, dtype=torch.float64, device=dev)
+        call('ofx_gn_stats', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
     call('ofx_gn_finalize', ptr(sums), ptr(count), batch_size, C, groups, eps, count_eps, ptr(mean), ptr(rstd),
          stream())
     if out is None:
@@ -284,6 +295,25 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
     b = bias.detach().reshape(-1)
     call('ofx_gn_apply', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(w), ptr(b),
          ACT[act], ptr(out), ldo, stream())
+    return out
+
+
+STATS_ATTR = '_ofx_gn_stats'
+
+
+def get_stats(t):
+    """GroupNorm sums attached to a tensor by the kernel epilogue that produced it (or None)."""
+    return getattr(t, STATS_ATTR, None)
+
+
+def cat_channels(a, b):
+    """torch.cat([a, b], dim=1) that also concatenates attached GroupNorm statistics."""
+    out = torch.cat([a, b], dim=1)
+    sa, sb = get_stats(a), get_stats(b)
+    if sa is not None and sb is not None:
+        B = sa.numel() // (a.shape[1] * 2)
+        st = torch.cat([sa.view(B, a.shape[1], 2), sb.view(B, b.shape[1], 2)], dim=1).contiguous().view(-1)
+        setattr(out, STATS_ATTR, st)
     return out
 
 

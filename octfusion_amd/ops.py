@@ -233,9 +233,20 @@ def gridconv(x, tables, n_out, pw, bias=None, emb=None, batch_id=None, res=None,
     _chk(bias)
     ws = workspace(x.device)
     fast = pw.cin % 32 == 0 and ldx % 4 == 0
+    prof = GRAPHCONV_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     call('ofx_gridconv_fwd', ptr(x), ldx, pw.cin, x.shape[0], n_out, None if fast else ptr(tables(False)),
          ptr(tables(True)) if fast else None, ptr(zero_row(x.device)), ptr(pw.t), pw.N, ptr(bias), ptr(emb), lde,
          ptr(batch_id) if emb is not None else None, ptr(res), ldr, ptr(out), ldc, ptr(ws), ws.numel(), stream())
+    if prof is not None:
+        e1.record()
+        # same kernel as the GraphConv (27 taps): algorithmic = one source row per tap + output + weights + indices
+        flops = 2.0 * n_out * 27 * pw.cin * pw.N
+        nbytes = 4.0 * (27.0 * n_out * pw.cin + n_out * pw.N + 27.0 * pw.cin * pw.N) + 4.0 * 27 * n_out
+        prof.append((e0, e1, flops, nbytes))
     return out
 
 

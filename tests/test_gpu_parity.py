@@ -441,3 +441,42 @@ def test_cascade_two_stage_runs():
     dec = out['decoded']
     assert set(dec['logits']) == {6, 7, 8} and dec['octree_out'].depth == 8
     assert all(bool(torch.isfinite(v).all()) for v in dec['reg_voxs'].values())
+
+
+def test_full_size_shell6_b8_properties():
+    """BASELINE-size input (shell-6, batch 8: N6 = 217 008, E6 = 1 629 600): one fused GraphConv and one
+    DualOctreeGroupNorm against the CPU oracle, plus size-independent properties (linearity of the
+    convolution; zero mean / unit variance per (batch element, group) after the norm)."""
+    from octfusion_amd import modules as M, synthetic
+    from oracle import dual_octree as OD, modules as OM, sampler as OS
+    split = synthetic.shell6_split(8, jitter=True)
+    oc, doc = build(split, 6, 4)
+    assert doc.csr(6)[2] == 217008 and doc.csr(6)[3] == 1629600
+    o_doc = OD.OracleDualOctree(OS.split2octree_small(split, 6, 4))
+    o_doc.post_processing_for_docnn()
+    a = canon(doc.graph[6]['edge_idx'], doc.graph[6]['edge_dir'])
+    b = OD.canonical_edges(o_doc.graph[6]['edge_idx'], o_doc.graph[6]['edge_dir'])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])            # bit-exact neighbour indices
+    N = doc.csr(6)[2]
+    conv = M.GraphConv(128, 128, 7, 7, 5)
+    sd = C.fill_state_dict([(k, tuple(v.shape)) for k, v in conv.state_dict().items()])
+    conv.load_state_dict(sd)
+    conv = conv.to(dev())
+    x = C.rand_input('full', N, 128)
+    y = conv(x.to(dev()), doc, 6)
+    close(y, OM.graph_conv(x, o_doc, 6, sd['weights'], None, 5), 1e-4)
+    # linearity: conv(2x + z) - type term == 2 conv(x) + conv(z) - 2 * type term  <=>  check on differences
+    z = C.rand_input('full_z', N, 128).to(dev())
+    zero = conv(torch.zeros_like(z), doc, 6)                               # = node-type contribution only
+    lhs = conv(2 * x.to(dev()) + z, doc, 6) - zero
+    rhs = 2 * (y - zero) + (conv(z, doc, 6) - zero)
+    close(lhs, rhs, 1e-4)
+    gn = M.DualOctreeGroupNorm(128).to(dev())
+    g = gn(y, doc, 6)
+    bid = doc.batch_id(6)
+    for bidx in (0, 3, 7):
+        rows = g[bid == bidx].view(-1, 32, 4)
+        assert float(rows.mean(dim=(0, 2)).abs().max()) < 1e-4
+        assert float((rows.var(dim=(0, 2), unbiased=False) - 1).abs().max()) < 1e-3
+    gw = OM.dual_octree_group_norm(y.cpu(), o_doc, 6, torch.ones(1, 128), torch.zeros(1, 128))
+    close(g, gw, 1e-4)

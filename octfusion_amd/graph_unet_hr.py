@@ -80,6 +80,8 @@ class UNet3DModel(nn.Module):
                 blocks.append(GraphDownsample(ch, ch, et, deg, d - 2))
             skip_ch.append(ch)
         self.input_blocks = nn.ModuleList(blocks)
+        self._skip_ch_all = list(skip_ch)
+        self._mid_out_ch = ch
         d_mid = input_depth - (len(self.channel_mult) - 1)
         self._d_mid = d_mid
         self.middle_block1 = res(ch, lr_model_channels, d_mid)
@@ -95,6 +97,18 @@ class UNet3DModel(nn.Module):
                 outs.append(GraphUpsample(ch, ch, et, deg, d))
         self.output_blocks = nn.ModuleList(outs)
 
+        # (C_h, C_skip, depth) of the decoder concat that consumes skip i (production order), for forward()
+        skip_depths = [input_depth] + [(dd if kind == 'res' else dd - 1) for kind, dd, _ in enc]
+        plan = []
+        ch_run = self._mid_out_ch
+        sk = list(self._skip_ch_all)
+        for kind, dd, level in dec:
+            if kind == 'res':
+                c_skip = sk.pop()
+                plan.append((ch_run, c_skip, dd))
+                ch_run = model_channels * self.channel_mult[level]
+        self._cat_plan = list(reversed(plan))
+        assert [p_[2] for p_ in self._cat_plan] == skip_depths, (self._cat_plan, skip_depths)
         self.end_norm = graphnormalization(ch)
         self.end = nn.SiLU()
         self.out = GraphConv(ch, out_channels, et, deg, input_depth - 1)
@@ -119,14 +133,34 @@ class UNet3DModel(nn.Module):
             emb = emb + self.label_emb(label)
         emb_act = ops.act(emb, 'silu')          # SiLU(emb) is what every res-block consumes
 
+        # Zero-copy skip concatenation: the decoder block that consumes skip tensor i reads ONE buffer
+        # [N, C_h + C_skip]; the encoder module that produces the skip writes straight into its right
+        # columns and the decoder module that produces h into its left columns (every libofx kernel takes
+        # a leading dimension), so torch.cat never copies activations.
+        dev = x.device
+        n_at = {dd: doctree.csr(dd)[2] for dd in range(self._d_mid, self.input_depth + 1)}
+        cat_bufs = []                     # one per skip tensor, in production order
+        for (c_h, c_skip, dd) in self._cat_plan:
+            cat_bufs.append(torch.empty(n_at[dd], c_h + c_skip, dtype=torch.float32, device=dev))
+
+        def skip_slot(i):
+            c_h, c_skip, _ = self._cat_plan[i]
+            return cat_bufs[i][:, c_h:]
+
         d = self.input_depth
-        h = x if as_middle else self.input_blocks[0](x, doctree, d)
-        hs = [h]
-        for (kind, dd, _), module in zip(self._enc, self.input_blocks[1:]):
+        if as_middle:
+            h = x
+            ops.rows_copy(x, skip_slot(0), x.shape[0])
+            hs = [skip_slot(0)]
+        else:
+            h = self.input_blocks[0](x, doctree, d, out=skip_slot(0))
+            hs = [h]
+        for k, ((kind, dd, _), module) in enumerate(zip(self._enc, self.input_blocks[1:])):
+            slot = skip_slot(k + 1)
             if kind == 'res':
-                h = module(h, emb, doctree, dd, emb_act=emb_act)
+                h = module(h, emb, doctree, dd, emb_act=emb_act, out=slot)
             else:
-                h = module(h, doctree, dd)
+                h = module(h, doctree, dd, out=slot)
             hs.append(h)
         d = self._d_mid
 
@@ -136,12 +170,33 @@ class UNet3DModel(nn.Module):
             h = ops.cat_channels(h, h_lr)
             h = self.middle_block2(h, emb, doctree, d, emb_act=emb_act)
 
-        for (kind, dd, _), module in zip(self._dec, self.output_blocks):
+        # decoder: block j consumes skip len(hs)-1-j; its own output goes to the left columns of the NEXT
+        # consumer's buffer when the next module is a res block
+        n_skip = len(hs)
+        j = 0                             # skips consumed so far
+        pending = h                       # tensor that will become the left half of the next concat
+        for idx, ((kind, dd, _), module) in enumerate(zip(self._dec, self.output_blocks)):
+            nxt_is_res = idx + 1 < len(self._dec) and self._dec[idx + 1][0] == 'res'
+            out_slot = None
+            if nxt_is_res:
+                c_h_n = self._cat_plan[n_skip - 1 - (j + (1 if kind == 'res' else 0))][0]
+                out_slot = cat_bufs[n_skip - 1 - (j + (1 if kind == 'res' else 0))][:, :c_h_n]
             if kind == 'res':
-                h = ops.cat_channels(h, hs.pop())
-                h = module(h, emb, doctree, dd, emb_act=emb_act)
+                si = n_skip - 1 - j
+                c_h = self._cat_plan[si][0]
+                left = cat_bufs[si][:, :c_h]
+                if pending.data_ptr() != left.data_ptr():          # first decoder block: h came from the middle
+                    ops.rows_copy(pending, left, pending.shape[0])
+                    st = ops.get_stats(pending)
+                    if st is not None:
+                        setattr(left, ops.STATS_ATTR, st)
+                    pending = left
+                hcat = ops.cat_channels(pending, hs[si], buf=cat_bufs[si])
+                pending = module(hcat, emb, doctree, dd, emb_act=emb_act, out=out_slot)
+                j += 1
             else:
-                h = module(h, doctree, dd)
+                pending = module(pending, doctree, dd, out=out_slot)
+        h = pending
         h = self.end_norm(h, doctree, self.input_depth, act='silu')
         if as_middle:
             return h

@@ -253,8 +253,8 @@ class GraphDownsample(nn.Module):
         self.downsample = Downsample(channels_in)
         self.conv = GraphConv(channels_in, channels_out, n_edge_type, avg_degree, n_node_type)
 
-    def forward(self, x, doctree, d):
-        return self.conv(pool_nodes(x, doctree, d, self.downsample), doctree, d - 1)
+    def forward(self, x, doctree, d, out=None):
+        return self.conv(pool_nodes(x, doctree, d, self.downsample), doctree, d - 1, out=out)
 
 
 class GraphUpsample(nn.Module):
@@ -267,8 +267,8 @@ class GraphUpsample(nn.Module):
         self.upsample = Upsample(channels_in)
         self.conv = GraphConv(channels_in, channels_out, n_edge_type, avg_degree, n_node_type)
 
-    def forward(self, x, doctree, d):
-        return self.conv(unpool_nodes(x, doctree, d, self.upsample), doctree, d + 1)
+    def forward(self, x, doctree, d, out=None):
+        return self.conv(unpool_nodes(x, doctree, d, self.upsample), doctree, d + 1, out=out)
 
 
 def graphnormalization(channels):
@@ -308,8 +308,9 @@ class GraphResBlockEmbed(TimestepBlock):
             self.skip_connection = Conv1x1(self.channels, self.out_channels)
 
     @torch.no_grad()
-    def forward(self, x, emb, doctree, depth, emb_act=None):
-        """``emb_act``: optional precomputed SiLU(emb) shared by all blocks of a step."""
+    def forward(self, x, emb, doctree, depth, emb_act=None, out=None):
+        """``emb_act``: optional precomputed SiLU(emb) shared by all blocks of a step; ``out``: optional
+        destination (may be a column slice of a wider buffer: zero-copy skip concatenation)."""
         h = self.block1_norm(x, doctree, depth, act='silu')
         if emb_act is None:
             emb_act = ops.act(emb, 'silu')
@@ -318,7 +319,7 @@ class GraphResBlockEmbed(TimestepBlock):
         h = self.conv1(h, doctree, depth, emb=emb_out)              # + emb_out[batch_id] fused
         h = self.block2_norm(h, doctree, depth, act='silu', out=h)
         skip = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x)
-        return self.conv2(h, doctree, depth, res=skip)              # skip + h fused
+        return self.conv2(h, doctree, depth, res=skip, out=out)     # skip + h fused
 
 
 class GraphResBlock(nn.Module):

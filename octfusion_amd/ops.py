@@ -187,7 +187,7 @@ def graphconv(x, nbr, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None
         flops = 2.0 * N * k_logical * pw.N
         # fused-op algorithmic bytes: one feature row per edge + output + weights + 8 B/edge
         nbytes = 4.0 * (E * cin + N * pw.N + k_logical * pw.N) + 8.0 * E
-        prof.append((e0, e1, flops, nbytes))
+        prof.append((e0, e1, flops, nbytes, pw.N))
     return out
 
 
@@ -317,9 +317,10 @@ def get_stats(t):
     return getattr(t, STATS_ATTR, None)
 
 
-def cat_channels(a, b):
-    """torch.cat([a, b], dim=1) that also concatenates attached GroupNorm statistics."""
-    out = torch.cat([a, b], dim=1)
+def cat_channels(a, b, buf=None):
+    """torch.cat([a, b], dim=1) that also concatenates attached GroupNorm statistics.  If `buf` is given,
+    a and b are already the left / right column slices of it (zero-copy) and only the statistics are merged."""
+    out = buf if buf is not None else torch.cat([a, b], dim=1)
     sa, sb = get_stats(a), get_stats(b)
     if sa is not None and sb is not None:
         B = sa.numel() // (a.shape[1] * 2)

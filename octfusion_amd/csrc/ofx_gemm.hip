@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
   // MFMA block and pinned there); the loop is unrolled by two over alternating fragment / index
   // register sets so that nothing is copied (a copy would wait for its load).
   if (g_begin < g_end) {
-    RegSet R;
+    RegSet R0, R1;
     IdxSet I0 = {0, 0, 0, 0}, I1 = {0, 0, 0, 0};
     BFrag F0, F1;
     auto clampg = [&](int it) { return it < nkt_g ? it : nkt_g - 1; };
@@ -780,7 +780,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
       const int dc = clampg(it) % ndir;
       I.i0 = (uint32_t)t0[dc]; I.i1 = (uint32_t)t1[dc]; I.i2 = (uint32_t)t2[dc]; I.i3 = (uint32_t)t3[dc];
     };
-    auto load_rows = [&](int it, const IdxSet& I) {
+    auto load_rows = [&](int it, const IdxSet& I, RegSet& R) {
       const int itc = clampg(it);
       if (MODE == MODE_DENSE) {
         int cc = itc * BK + c4 * 4;
@@ -794,34 +794,94 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
         R.a3 = ldg4(xp + src_off(I.i3, ldx, n_src, aux_delta) + cc);
       }
     };
-    // one pipeline step: tile `it` is computed with Fcur; Iuse = indices of tile it+1
-    auto step = [&](int it, int buf, const IdxSet& Iuse, IdxSet& Iload, const BFrag& Fcur, BFrag& Fnext) {
-      load_idx(it + 2, Iload);
-      __builtin_amdgcn_sched_barrier(0);      // index loads stay OLDER than the row loads (counted vmcnt)
-      load_rows(it + 1, Iuse);
-      load_bfrag(ktw_of(it + 1), Fnext);
-      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch above the MFMA block
-      compute(buf, Fcur);
-      __builtin_amdgcn_sched_barrier(0);
-      store_a(buf ^ 1, R);                    // A rows of tile it+1 -> LDS
+    auto load_bchunk = [&](int ktw, int c, BFrag& F) {
+      const gqp wk = w16 + (int64_t)ktw * 4 * Ncols + (int64_t)(2 * c) * Ncols;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) { F.h[c][j] = wk[bcol[j]]; F.l[c][j] = wk[lo_off + bcol[j]]; }
+    };
+    auto store_half = [&](int buf, const float4& v0, const float4& v1, int row_off) {
+      char* a = a_st + buf * BUF_BYTES + row_off * 80;
+      uint2 hi, lo;
+      split_bf16x4(v0, hi, lo);
+      *reinterpret_cast<uint2*>(a) = hi; *reinterpret_cast<uint2*>(a + A_BYTES) = lo;
+      split_bf16x4(v1, hi, lo);
+      *reinterpret_cast<uint2*>(a + 32 * 80) = hi; *reinterpret_cast<uint2*>(a + 32 * 80 + A_BYTES) = lo;
+    };
+#define OFX_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // One pipeline step computes tile `it` from LDS buffer `buf` with weight fragments Fcur.
+    // In flight: A rows TWO tiles ahead (requested into Rnew; Rold = tile it+1 is converted and written to
+    // LDS in this step), weight fragments one tile ahead (Fnext), indices three tiles ahead.
+    // The 24 MFMAs are issued as six groups of four; every other piece of work (index loads, fragment
+    // loads, row gathers, bf16 split + LDS stores) sits BETWEEN groups, pinned by fences, so it issues in
+    // the shadow of the preceding group's 128 matrix-pipe cycles.  (Measured before this interleave, per
+    // wave per step: 1279 cycles issuing the prefetch, 979 in the MFMA block, 356 storing -- serial.)
+    auto step = [&](int it, int buf, const IdxSet& Iuse, IdxSet& Iload, const BFrag& Fcur, BFrag& Fnext,
+                    RegSet& Rnew, const RegSet& Rold) {
+      const char* a = a_ld + buf * BUF_BYTES;
+      const int ktw = ktw_of(it + 1);
+      bf16x8_t ah[2][MI], al[2][MI];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          ah[c][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + 32 * c);
+          al[c][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + 32 * c + A_BYTES);
+        }
+      load_idx(it + 3, Iload);
+      OFX_FENCE();
+#define OFX_MFMA_GROUP(AOP, BOP, C)                                                                        \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                        \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                      \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AOP[C][i], __builtin_bit_cast(bf16x8_t, Fcur.BOP[C][j]), acc[i][j], 0, 0, 0);
+      OFX_MFMA_GROUP(al, h, 0);
+      OFX_FENCE();
+      load_bchunk(ktw, 0, Fnext);
+      OFX_FENCE();
+      OFX_MFMA_GROUP(ah, l, 0);
+      OFX_FENCE();
+      load_bchunk(ktw, 1, Fnext);
+      OFX_FENCE();
+      OFX_MFMA_GROUP(ah, h, 0);
+      OFX_FENCE();
+      load_rows(it + 2, Iuse, Rnew);
+      OFX_FENCE();
+      OFX_MFMA_GROUP(al, h, 1);
+      OFX_FENCE();
+      store_half(buf ^ 1, Rold.a0, Rold.a1, 0);        // tile it+1, requested during the previous step
+      OFX_FENCE();
+      OFX_MFMA_GROUP(ah, l, 1);
+      OFX_FENCE();
+      store_half(buf ^ 1, Rold.a2, Rold.a3, 64);
+      OFX_FENCE();
+      OFX_MFMA_GROUP(ah, h, 1);
+#undef OFX_MFMA_GROUP
       __syncthreads();
     };
 
+    // prologue (same issue order as the steady state: indices, then rows / fragments)
     load_idx(g_begin, I0);
     load_idx(g_begin + 1, I1);
-    __builtin_amdgcn_sched_barrier(0);
-    load_rows(g_begin, I0);
-    load_bfrag(ktw_of(g_begin), F0);
-    __builtin_amdgcn_sched_barrier(0);
-    store_a(0, R);
+    OFX_FENCE();
+    load_rows(g_begin, I0, R0);
+    load_bchunk(ktw_of(g_begin), 0, F0);
+    load_bchunk(ktw_of(g_begin), 1, F0);
+    OFX_FENCE();
+    load_idx(g_begin + 2, I0);
+    OFX_FENCE();
+    load_rows(g_begin + 1, I1, R1);
+    OFX_FENCE();
+    store_half(0, R0.a0, R0.a1, 0);
+    store_half(0, R0.a2, R0.a3, 64);
     __syncthreads();
+    // steady state: Rold holds tile it+1, Iuse the indices of tile it+2
     int it = g_begin;
     for (; it + 1 < g_end; it += 2) {
-      step(it, 0, I1, I0, F0, F1);
-      step(it + 1, 1, I0, I1, F1, F0);
+      step(it, 0, I0, I1, F0, F1, R0, R1);
+      step(it + 1, 1, I1, I0, F1, F0, R1, R0);
     }
-    if (it < g_end) step(it, 0, I1, I0, F0, F1);
+    if (it < g_end) step(it, 0, I0, I1, F0, F1, R0, R1);
     __syncthreads();
+#undef OFX_FENCE
   }
 
   // ------------------------------------------------------------ node-type slab tiles

@@ -31,6 +31,9 @@ for d, cin, cout in [(6, 128, 128), (6, 256, 256), (5, 256, 256), (4, 512, 512)]
     x = torch.randn(N, cin, device=dev)
     flops = 2.0 * N * 7 * (cin + d - 1) * cout
     t = timeit(lambda: conv(x, doc, d))
+    conv.emit_stats = False
+    t_nostats = timeit(lambda: conv(x, doc, d))
+    conv.emit_stats = True
     nbr_ext, multi_seg, V = doc.ext(d)
     # variant: every (row, dir) gathers the row itself (perfect locality, same instruction stream)
     self_tab = torch.arange(N, device=dev, dtype=torch.int32).repeat_interleave(7).contiguous()
@@ -46,5 +49,5 @@ for d, cin, cout in [(6, 128, 128), (6, 256, 256), (5, 256, 256), (4, 512, 512)]
     A = torch.randn(N, 7 * cin, device=dev)
     pw = ops.PackedWeight().get(torch.randn(7 * cin, cout, device=dev), 'kn')
     t_dense = timeit(lambda: ops.gemm(A, pw))
-    print('d%d N=%d cin=%d cout=%d: graph %.3f ms (%.0f TF)  self-gather %.3f ms  random-gather %.3f ms  dense %.3f ms (%.0f TF)'
-          % (d, N, cin, cout, t, flops / t / 1e9, t_self, t_rnd, t_dense, 2.0 * N * 7 * cin * cout / t_dense / 1e9))
+    print('d%d N=%d cin=%d cout=%d: graph %.3f ms (%.0f TF)  no-stats %.3f ms  self-gather %.3f ms  random-gather %.3f ms  dense %.3f ms (%.0f TF)'
+          % (d, N, cin, cout, t, flops / t / 1e9, t_nostats, t_self, t_rnd, t_dense, 2.0 * N * 7 * cin * cout / t_dense / 1e9))

@@ -204,13 +204,13 @@ def main():
 
     if rank == 0 and os.environ.get('OFX_BENCH_VERBOSE'):
         agg = {}
-        for a, b, f, nb, _ in prof:
-            k = (f, nb)
+        for a, b, f, nb, _, shp in prof:
+            k = (f, nb, shp)
             t, c = agg.get(k, (0.0, 0))
             agg[k] = (t + a.elapsed_time(b), c + 1)
-        for (f, nb), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-            print('conv flops %.3e bytes %.3e  n=%3d  avg %.3f ms  %.1f TF/s  %.0f GB/s' %
-                  (f, nb, c, t / c, f * c / t / 1e9, nb * c / t / 1e6), file=sys.stderr)
+        for (f, nb, shp), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            print('%-28s flops %.3e bytes %.3e  n=%3d  avg %.3f ms  total %.2f ms  %.1f TF/s  %.0f GB/s' %
+                  (shp, f, nb, c, t / c, t, f * c / t / 1e9, nb * c / t / 1e6), file=sys.stderr)
     if rank == 0:
         # dominant kernel: the fused GraphConv.  Default contraction = bf16x3 on the bf16 matrix pipe:
         # every algorithmic fp32 multiply-add costs 3 bf16 MFMA multiply-adds, so the matrix-pipe roof for
@@ -219,9 +219,9 @@ def main():
         bf16x3 = _L.lib().ofx_get_precision() == 0
         # the dominant kernel SYMBOL is the BN = 128 instantiation (output width > 64): restrict to it so the
         # average launch time is comparable with the rocprofv3 --stats line of the same name
-        all_ms = sum(a.elapsed_time(b) for a, b, _, _, _ in prof)
+        all_ms = sum(a.elapsed_time(b) for a, b, *_ in prof)
         dom = [p_ for p_ in prof if p_[4] > 64]
-        t_ms = sum(a.elapsed_time(b) for a, b, _, _, _ in dom)
+        t_ms = sum(a.elapsed_time(b) for a, b, *_ in dom)
         flops = sum(p_[2] for p_ in dom)
         nbytes = sum(p_[3] for p_ in dom)
         launches = len(dom)

@@ -1387,6 +1387,52 @@ static int gather_common(GemmArgs& g, const float* x, int64_t ldx, int cin, int 
   return OFX_OK;
 }
 
+// Layers the branch-free gather kernel cannot take (Cin not a multiple of 32: the network's input conv with
+// Cin = 3, the VAE decoder's 24/32-channel convs): materialise the reference's col_data rows
+// [rows, Kp] = [7 (27) segment means | node-type slab] into the workspace, one row chunk at a time, and run
+// the dense kernel on them with the same packed weights (their k order is exactly this layout).
+__global__ void __launch_bounds__(256) col_rows_kernel(const GemmArgs g, int64_t row0, int64_t rows,
+                                                       float* __restrict__ colbuf) {
+  const int64_t k4n = g.Kp >> 2, total = rows * k4n;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / k4n, k = (t - r * k4n) * 4;
+    const int64_t row = row0 + r;
+    float v[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      v[kk] = (k + kk < g.Kf) ? gather_elem(g, row, k + kk) : g.tf[row * g.ldt + (k + kk - g.Kf)];
+    *reinterpret_cast<float4*>(colbuf + t * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+template <int MODE> static int launch_gemm(GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st);
+
+// returns OFX_OK when it handled the layer, -1 when the workspace is too small (caller uses the generic kernel)
+static int launch_gather_via_col(const GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st) {
+  if (!ws || (((uintptr_t)ws) & 15)) return -1;
+  size_t tail = ws_bytes / 8;                                  // split-K partials / statistics partials
+  if (tail > (size_t(16) << 20)) tail = size_t(16) << 20;
+  tail &= ~size_t(15);
+  const size_t row_bytes = (size_t)g.Kp * sizeof(float);
+  int64_t chunk = (int64_t)((ws_bytes - tail) / row_bytes) / 128 * 128;
+  if (chunk < 128) return -1;
+  float* tail_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (ws_bytes - tail));
+  for (int64_t r0 = 0; r0 < g.M; r0 += chunk) {
+    const int64_t rows = g.M - r0 < chunk ? g.M - r0 : chunk;
+    col_rows_kernel<<<ofx_grid(rows * (g.Kp >> 2), 256), 256, 0, st>>>(g, r0, rows, ws);
+    GemmArgs d = {};
+    d.A = ws; d.lda = g.Kp; d.M = rows; d.K = g.Kp; d.Wp = g.Wp; d.Kp = g.Kp; d.N = g.N; d.bias = g.bias;
+    d.emb = g.emb; d.lde = g.lde; d.bid = g.bid ? g.bid + r0 : nullptr;
+    d.res = g.res ? g.res + r0 * g.ldr : nullptr; d.ldr = g.ldr;
+    d.out = g.out + r0 * g.ldc; d.ldc = g.ldc;
+    d.stats = g.stats; d.stats_ld = g.stats_ld;
+    if (g.stats) { d.stats_part = tail_ws; d.stats_part_bytes = tail; }
+    const int rc = launch_gemm<MODE_DENSE>(d, g.stats ? nullptr : tail_ws, tail, st);
+    if (rc) return rc;
+  }
+  return OFX_OK;
+}
+
 extern "C" int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes, const int32_t* nbr,
                                  const int32_t* seg_ptr, const int32_t* col, const int32_t* nbr_ext,
                                  const int32_t* multi_seg, int64_t n_multi, float* aux, const float* type_frac,
@@ -1417,6 +1463,11 @@ extern "C" int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n
     g.nbr_ext = nbr_ext; g.aux = aux; g.ldaux = ldx; g.n_src = n_nodes;
     if (!g.tf) { g.tf = x; g.ldt = ldx; }       // never dereferenced past the gather tiles; keeps selects defined
   }
+  if (!g.nbr_ext && n_nodes > 0) {
+    // stats set `ws` aside for the partial sums: the col path manages the whole workspace itself
+    rc = launch_gather_via_col(g, stats ? g.stats_part : (float*)ws, stats ? g.stats_part_bytes : ws_bytes, st);
+    if (rc >= 0) return rc;
+  }
   return launch_gemm<MODE_GATHER>(g, (float*)ws, ws_bytes, st);
 }
 
@@ -1437,6 +1488,10 @@ extern "C" int ofx_gridconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_
     g.tf = x; g.ldt = ldx;
   } else if (!nbr27) {
     return OFX_EINVAL;            // generic path needs the -1-padded table
+  }
+  if (!g.nbr_ext) {
+    rc = launch_gather_via_col(g, (float*)ws, ws_bytes, ofx_stream(stream));
+    if (rc >= 0) return rc;
   }
   return launch_gemm<MODE_GATHER>(g, (float*)ws, ws_bytes, ofx_stream(stream));
 }

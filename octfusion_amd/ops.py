@@ -187,7 +187,7 @@ def graphconv(x, nbr, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None
         flops = 2.0 * N * k_logical * pw.N
         # fused-op algorithmic bytes: one feature row per edge + output + weights + 8 B/edge
         nbytes = 4.0 * (E * cin + N * pw.N + k_logical * pw.N) + 8.0 * E
-        prof.append((e0, e1, flops, nbytes, pw.N))
+        prof.append((e0, e1, flops, nbytes, pw.N, ('graph', N, cin, pw.N)))
     return out
 
 
@@ -246,7 +246,7 @@ def gridconv(x, tables, n_out, pw, bias=None, emb=None, batch_id=None, res=None,
         # same kernel as the GraphConv (27 taps): algorithmic = one source row per tap + output + weights + indices
         flops = 2.0 * n_out * 27 * pw.cin * pw.N
         nbytes = 4.0 * (27.0 * n_out * pw.cin + n_out * pw.N + 27.0 * pw.cin * pw.N) + 4.0 * 27 * n_out
-        prof.append((e0, e1, flops, nbytes, pw.N))
+        prof.append((e0, e1, flops, nbytes, pw.N, ('grid', n_out, pw.cin, pw.N)))
     return out
 
 

@@ -123,6 +123,10 @@ class UNet3DModel(nn.Module):
     @torch.no_grad()
     def forward(self, x=None, doctree=None, unet_lr=None, timesteps=None, label=None, context=None,
                 as_middle=False, **kwargs):
+        with ops.stats_scope(x.device):           # one zero-fill for every fused GroupNorm statistics buffer
+            return self._forward(x, doctree, unet_lr, timesteps, label, context, as_middle)
+
+    def _forward(self, x, doctree, unet_lr, timesteps, label, context, as_middle):
         assert (label is not None) == (self.num_classes is not None), \
             'must specify y if and only if the model is class-conditional'
         t_emb = ops.timestep_embedding(timesteps.float(), self.model_channels)

@@ -69,9 +69,8 @@ class GraphConv(nn.Module):
         tf = doctree.type_frac(d, nt) if nt else None
         # large outputs feed a DualOctreeGroupNorm next: let the epilogue accumulate its statistics
         stats = None
-        if self.emit_stats and self.in_channels % 32 == 0 and N * self.out_channels >= (1 << 20) \
-                and self.out_channels % 4 == 0:
-            stats = torch.zeros(doctree.batch_size * self.out_channels * 2, dtype=torch.float64, device=x.device)
+        if self.emit_stats and N * self.out_channels >= (1 << 20) and self.out_channels % 4 == 0:
+            stats = ops.stats_zeros(doctree.batch_size * self.out_channels * 2, x.device)
         y = ops.graphconv(x, doctree.nbr(d), seg_ptr, col, pw, self.in_channels, tf,
                           self.bias if self.use_bias else None, emb,
                           doctree.batch_id32(d) if (emb is not None or stats is not None) else None, res, out,

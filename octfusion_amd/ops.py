@@ -4,6 +4,7 @@ Every function here launches hand-written HIP kernels from libofx.so on the
 current torch HIP stream.  Inputs must be CUDA (HIP) tensors; nothing here has
 a CPU implementation -- a CPU tensor raises.
 """
+import contextlib
 import torch
 
 from . import _lib
@@ -312,9 +313,55 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
 STATS_ATTR = '_ofx_gn_stats'
 
 
+class _StatsPool:
+    """Zero-initialised fp64 slices for the fused GroupNorm statistics: one fill per network forward instead
+    of one per GraphConv (each tiny fill costs a full launch slot on the stream)."""
+    SIZE = 1 << 19                      # doubles (4 MB)
+
+    def __init__(self):
+        self.buf = None
+        self.cur = 0
+        self.depth = 0
+        self.gen = 0
+
+
+_stats_pool = _StatsPool()
+
+
+@contextlib.contextmanager
+def stats_scope(device):
+    """Buffers handed out by stats_zeros() inside the (outermost) scope come from one pre-zeroed pool; they are
+    valid until the next outermost scope begins (get_stats() drops stale ones)."""
+    p = _stats_pool
+    if p.depth == 0:
+        if p.buf is None or p.buf.device != device:
+            p.buf = torch.empty(p.SIZE, dtype=torch.float64, device=device)
+        p.buf.zero_()
+        p.cur = 0
+        p.gen += 1
+    p.depth += 1
+    try:
+        yield
+    finally:
+        p.depth -= 1
+
+
+def stats_zeros(n, device):
+    p = _stats_pool
+    if p.depth > 0 and p.buf.device == device and p.cur + n <= p.SIZE:
+        st = p.buf[p.cur:p.cur + n]
+        p.cur += (n + 1) & ~1           # keep 16-B alignment
+        st._ofx_gen = p.gen
+        return st
+    return torch.zeros(n, dtype=torch.float64, device=device)
+
+
 def get_stats(t):
     """GroupNorm sums attached to a tensor by the kernel epilogue that produced it (or None)."""
-    return getattr(t, STATS_ATTR, None)
+    st = getattr(t, STATS_ATTR, None)
+    if st is not None and getattr(st, '_ofx_gen', _stats_pool.gen) != _stats_pool.gen:
+        return None                     # pooled slice from an earlier forward: recycled since
+    return st
 
 
 def cat_channels(a, b, buf=None):

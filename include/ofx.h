@@ -134,6 +134,20 @@ int ofx_graph_expand(const int32_t* seg_ptr, int64_t n_nodes, const int32_t* col
 /* nbr[r*7+dir] = the single neighbour of segment (r,dir), -1 if none, -2 if several. */
 int ofx_graph_primary(const int32_t* seg_ptr, const int32_t* col, int64_t n_nodes, int32_t* nbr,
                       void* stream);
+/* NeuralMPU SDF evaluation -- replaces NeuralMPU.__call__ / get_linear_pred / octree_linear_pts
+ * (models/networks/dualoctree_networks/mpu.py:55-153), spmm / modulated_spmm (utils/spmm.py:12-61) and, with the
+ * _grid entry, the sampling loop of calc_sdf (utils/util_dualoctree.py:99-118).
+ * pts [n,4] fp32 = (x, y, z in [-1,1], batch id).  For every depth d in [depth_start, depth_end] the 8 cell
+ * centres around the point that exist in the tree (and are leaves when d < depth_end) contribute
+ * w = prod(1-|f|) * d^2/50 and w * (code[row] . [f*2/2^d, 1]); sdf = sum / (sum w + 1e-8);
+ * mask[i] = 1 iff a centre of depth_end exists.  code rows: nodes of depth_start..depth_end concatenated
+ * (row = index in depth d + sum_{l<d} nnum[l]), 16-B aligned.  mask may be NULL.
+ * _grid: point q = head + i of the size^3 lattice (x slowest), coordinate = fl(fl(i*step) + bbmin). */
+int ofx_mpu_eval(const ofx_tree_t* tree, int depth_start, int depth_end, const float* pts, int64_t n_pts,
+                 const float* code, float* sdf, uint8_t* mask, void* stream);
+int ofx_mpu_eval_grid(const ofx_tree_t* tree, int depth_start, int depth_end, const float* code, int size,
+                      float step, float bbmin, int batch_index, int64_t head, int64_t count, float* sdf,
+                      uint8_t* mask, void* stream);
 /* Extended table for the branch-free kernel: flag[s] = segment s has > 1 neighbours;
  * with rank = exclusive scan of flag: nbr_ext[s] = neighbour id | N (none: zero row) |
  * N + 1 + rank[s] (several: pre-averaged row), multi_seg[rank[s]] = s. */

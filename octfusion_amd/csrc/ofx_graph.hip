@@ -384,3 +384,153 @@ extern "C" int ofx_graph_primary_ext(const int32_t* seg_ptr, const int32_t* col,
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
+
+// ---------------------------------------------------------------------------------
+// NeuralMPU SDF evaluation (reference models/networks/dualoctree_networks/mpu.py:55-153 with the two sparse
+// products of utils/spmm.py:12-61 folded in; sweep driver utils/util_dualoctree.py:99-118).
+// Eight lanes per query point, one per surrounding cell centre.  Per depth the lane needs the octree node of
+// its cell: at the first depth it walks down from the dense full layer; afterwards the parent of every
+// depth-(d+1) centre is one of the point's eight depth-d centres (base_{d+1} in {2b, 2b+1, 2b+2}), so the
+// node index comes from a neighbouring lane's previous result with ONE child lookup -- no key search, no sort,
+// no scatter: the reference's search_key + index_select + scatter_add chain collapses into registers.
+// HBM-bound: 16 B per point in (or nothing for the grid sweep), 5 B out, child / code gathers mostly from L2.
+struct MpuArgs {
+  TreeDev T;
+  int ds, de;
+  const float* pts;          // [n, 4] (x, y, z in [-1, 1], batch id) or NULL for the grid sweep
+  int64_t n;
+  const float* code;         // [sum_{d=ds..de} nnum[d], 4]
+  float* sdf;
+  uint8_t* mask;
+  int size, batch;           // grid sweep: point q = head + i, (ix, iy, iz) = unravel(q, size^3), x slowest
+  float step, bbmin;
+  int64_t head;
+};
+
+__device__ __forceinline__ int64_t mpu_walk(const TreeDev& T, int d, int x, int y, int z, int b) {
+  const int fd = T.full_depth < d ? T.full_depth : d;
+  int sh = d - fd;
+  int64_t idx = ((int64_t)b << (3 * fd)) + (int64_t)ofx_xyz2morton(x >> sh, y >> sh, z >> sh);
+  for (int s = fd; s < d; ++s) {
+    const int32_t c = T.child[T.ncum[s] + idx];
+    if (c < 0) return -1;
+    sh = d - s - 1;
+    idx = (int64_t)c * 8 + ((((x >> sh) & 1) << 2) | (((y >> sh) & 1) << 1) | ((z >> sh) & 1));
+  }
+  return idx;
+}
+
+__global__ void __launch_bounds__(256) mpu_eval_kernel(const MpuArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t q = t >> 3;
+  const int corner = (int)(t & 7);
+  const bool live = q < a.n;
+  const int64_t qc = live ? q : a.n - 1;
+  float px, py, pz;
+  int b;
+  if (a.pts) {
+    const float4 p = reinterpret_cast<const float4*>(a.pts)[qc];
+    px = p.x; py = p.y; pz = p.z; b = (int)p.w;
+  } else {
+    // samples = mgrid * ((bbmax - bbmin) / size) + bbmin in fp32, two roundings (util_dualoctree.py:102-103)
+    const int64_t g = a.head + qc;
+    const int64_t s2 = (int64_t)a.size * a.size;
+    const int ix = (int)(g / s2), iy = (int)((g / a.size) % a.size), iz = (int)(g % a.size);
+    float mx = (float)ix * a.step, my = (float)iy * a.step, mz = (float)iz * a.step;
+    asm volatile("" : "+v"(mx), "+v"(my), "+v"(mz));            // keep the product rounded: no fma contraction
+    px = mx + a.bbmin; py = my + a.bbmin; pz = mz + a.bbmin;
+    b = a.batch;
+  }
+  const int dx = (corner >> 2) & 1, dy = (corner >> 1) & 1, dz = corner & 1;      // mpu.py:37-52
+  const int lane_base = (int)(threadIdx.x & 63) & ~7;
+  float num = 0.f, den = 0.f;
+  bool found_last = false;
+  int64_t base_rows = 0;
+  int prev_idx = -1;
+  int pbx = 0, pby = 0, pbz = 0;
+  const bool bok = b >= 0 && b < a.T.batch_size;
+  for (int d = a.ds; d <= a.de; ++d) {
+    const int scale = 1 << d;
+    const float half = 0.5f * (float)scale;
+    // (p + 1) * scale/2 - 0.5: the product is exact (power of two), so contraction cannot change it
+    const float x = (px + 1.0f) * half - 0.5f, y = (py + 1.0f) * half - 0.5f, z = (pz + 1.0f) * half - 0.5f;
+    const float bxf = floorf(x), byf = floorf(y), bzf = floorf(z);
+    const int bx = (int)bxf, by = (int)byf, bz = (int)bzf;
+    const int cx = bx + dx, cy = by + dy, cz = bz + dz;
+    const float fx = x - (bxf + (float)dx), fy = y - (byf + (float)dy), fz = z - (bzf + (float)dz);
+    const bool inb = bok && cx >= 0 && cy >= 0 && cz >= 0 && cx < scale && cy < scale && cz < scale;
+    int idx = -1;
+    if (d == a.ds) {
+      if (inb) idx = (int)mpu_walk(a.T, d, cx, cy, cz, b);
+    } else {
+      const int pcx = (cx >> 1) - pbx, pcy = (cy >> 1) - pby, pcz = (cz >> 1) - pbz;
+      const bool pc_ok = (unsigned)pcx < 2u && (unsigned)pcy < 2u && (unsigned)pcz < 2u;
+      const int sl = (inb && pc_ok) ? ((pcx << 2) | (pcy << 1) | pcz) : 0;
+      const int pidx = __shfl(prev_idx, lane_base + sl);           // every lane takes part
+      if (inb && pc_ok) {
+        if (pidx >= 0) {
+          const int32_t c = a.T.child[a.T.ncum[d - 1] + pidx];
+          if (c >= 0) idx = c * 8 + (((cx & 1) << 2) | ((cy & 1) << 1) | (cz & 1));
+        }
+      } else if (inb) {
+        idx = (int)mpu_walk(a.T, d, cx, cy, cz, b);                // not reachable in exact arithmetic; kept for safety
+      }
+    }
+    const bool found = idx >= 0;
+    if (d == a.de) found_last = found;
+    bool use = found;
+    if (found && d < a.de) use = a.T.child[a.T.ncum[d] + idx] < 0;                // leaves only (mpu.py:113-116)
+    if (use) {
+      const float4 c = reinterpret_cast<const float4*>(a.code)[base_rows + idx];
+      const float s = 2.0f / (float)scale;
+      const float val = c.x * (fx * s) + c.y * (fy * s) + c.z * (fz * s) + c.w;
+      const float w = ((1.0f - fabsf(fx)) * (1.0f - fabsf(fy))) * (1.0f - fabsf(fz)) * (float)((double)(d * d) / 50.0);
+      num += w * val;
+      den += w;
+    }
+    prev_idx = idx;
+    pbx = bx; pby = by; pbz = bz;
+    base_rows += a.T.nnum[d];
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    num += __shfl_xor(num, o);
+    den += __shfl_xor(den, o);
+  }
+  const unsigned long long bal = __ballot(found_last);
+  if (corner == 0 && live) {
+    a.sdf[q] = num / (den + 1e-8f);
+    if (a.mask) a.mask[q] = ((bal >> ((threadIdx.x & 63) & ~7)) & 0xffull) ? 1 : 0;
+  }
+}
+
+static int mpu_launch(const ofx_tree_t* tree, MpuArgs& a, hipStream_t st) {
+  int rc = make_tree(tree, a.T);
+  if (rc) return rc;
+  if (a.ds < 0 || a.de < a.ds || a.de > a.T.depth || !a.code || !a.sdf || a.n < 0) return OFX_EINVAL;
+  if (((uintptr_t)a.code & 15) != 0) return OFX_EINVAL;
+  if (a.n == 0) return OFX_OK;
+  const int64_t threads = a.n * 8;
+  mpu_eval_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(a);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+extern "C" int ofx_mpu_eval(const ofx_tree_t* tree, int depth_start, int depth_end, const float* pts, int64_t n_pts,
+                            const float* code, float* sdf, uint8_t* mask, void* stream) {
+  if (!pts || ((uintptr_t)pts & 15) != 0 || n_pts > (int64_t(1) << 31)) return OFX_EINVAL;
+  MpuArgs a = {};
+  a.ds = depth_start; a.de = depth_end; a.pts = pts; a.n = n_pts; a.code = code; a.sdf = sdf; a.mask = mask;
+  return mpu_launch(tree, a, ofx_stream(stream));
+}
+
+extern "C" int ofx_mpu_eval_grid(const ofx_tree_t* tree, int depth_start, int depth_end, const float* code, int size,
+                                 float step, float bbmin, int batch_index, int64_t head, int64_t count, float* sdf,
+                                 uint8_t* mask, void* stream) {
+  if (size < 1 || head < 0 || count < 0 || head + count > (int64_t)size * size * size || count > (int64_t(1) << 31))
+    return OFX_EINVAL;
+  MpuArgs a = {};
+  a.ds = depth_start; a.de = depth_end; a.pts = nullptr; a.n = count; a.code = code; a.sdf = sdf; a.mask = mask;
+  a.size = size; a.batch = batch_index; a.step = step; a.bbmin = bbmin; a.head = head;
+  return mpu_launch(tree, a, ofx_stream(stream));
+}

@@ -11,7 +11,7 @@ SURVEY.md section 8: out of scope).  NeuralMPU SDF evaluation is the next row (s
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import mpu, ops
 from .dual_octree import DualOctree
 from .modules import (Conv1x1, Conv1x1GnGelu, Conv1x1GnGeluSequential, Downsample, DualOctreeGroupNorm,
                       GraphConv, GraphResBlocks, Upsample, pool_nodes, unpool_nodes)
@@ -64,6 +64,7 @@ class GraphVAE(nn.Module):
         super().__init__()
         self.depth, self.channel_in, self.nout = depth, channel_in, nout
         self.full_depth, self.depth_stop, self.depth_out = full_depth, depth_stop, depth_out
+        self.neural_mpu = mpu.NeuralMPU(full_depth, depth_stop, depth_out)          # graph_vae.py:69
         self.resblk_num = resblk_num
         self.channels = CHANNELS
         self.resblk_nums = [resblk_num] * 16
@@ -150,4 +151,9 @@ class GraphVAE(nn.Module):
         else:
             doctree_out = doctree_in
         out = self.octree_decoder(code, doctree_out, update_octree=update_octree)
-        return {'logits': out[0], 'reg_voxs': out[1], 'octree_out': out[2]}
+        output = {'logits': out[0], 'reg_voxs': out[1], 'octree_out': out[2]}
+        if pos is not None:                                     # graph_vae.py:316-317
+            output['mpus'] = self.neural_mpu(pos, out[1], out[2])
+        # graph_vae.py:319-323: the SDF field of the decoded shape (callable on pts [n,4]; calc_sdf sweeps it)
+        output['neural_mpu'] = mpu.MpuField(self.full_depth, self.depth_out, out[1][self.depth_out], out[2])
+        return output

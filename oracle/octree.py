@@ -11,7 +11,8 @@ constrained by the reference's own call sites:
 * child-octant bit order x->4, y->2, z->1 (dual_octree.py:85-94);
 * ``children < 0`` <=> leaf (dual_octree.py:72,203-204);
 * ``octree_grow`` does not bump ``depth`` (callers do ``octree.depth += 1``:
-  utils/util_dualoctree.py:239-240, graph_vae.py:207-208).
+  utils/util_dualoctree.py:239-240, graph_vae.py:207-208);
+* ``search_key(key, depth)`` returns the node index or -1 (mpu.py:72,78).
 
 Parity at this boundary is UNPINNED (no reference tests, dependency absent).
 """
@@ -113,6 +114,17 @@ class Octree:
 
     def nempty_mask(self, depth):
         return self.children[depth] >= 0
+
+    def search_key(self, query, depth, nempty=False):
+        """ocnn Octree.search_key (call site mpu.py:72): index of each query key in the sorted key list of
+        `depth`, -1 when absent.  Published algorithm (ocnn-pytorch octree.py): searchsorted + equality test."""
+        key = self.key(depth, nempty)
+        query = query.to(torch.int64)
+        idx = torch.searchsorted(key, query)
+        inside = idx < key.shape[0]
+        found = torch.zeros_like(inside)
+        found[inside] = key[idx[inside]] == query[inside]
+        return torch.where(found, idx, torch.full_like(idx, -1))
 
     # -- construction ----------------------------------------------------
     def octree_grow_full(self, depth, update_neigh=False):

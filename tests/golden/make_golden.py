@@ -371,7 +371,41 @@ def g_vae():
     save('g_vae', rec)
 
 
+# ---------------------------------------------------------------- G9
+def mpu_points(n, B, seed):
+    """Query points: uniform in the cube, plus points on / beyond cell-centre planes and the cube boundary."""
+    g = torch.Generator().manual_seed(seed)
+    p = torch.rand(n, 3, generator=g) * 2 - 1
+    p[: n // 8] = (torch.randint(0, 65, (n // 8, 3), generator=g).float() / 32 - 1)      # exact grid planes
+    p[n // 8: n // 6] = p[n // 8: n // 6].sign()                                         # cube corners / faces
+    b = torch.randint(0, B, (n, 1), generator=g).float()
+    return torch.cat([p, b], 1)
+
+
+def g_mpu():
+    """NeuralMPU (mpu.py) on the tiny depth-6 tree of g_vae: reference outputs for random per-node codes."""
+    from models.networks.dualoctree_networks import mpu as RMPU
+    split, oc, doc = tiny_doctree()
+    sl = C.random_split_large(int(oc.nnum[4]), 11, p=0.3)
+    oc_l = split2octree_large(oc, sl, 4)
+    full_depth, depth_stop, depth = 2, 4, 6
+    ncum = torch.cumsum(oc_l.nnum, 0)
+    reg = {d: C.rand_input('mpu_code_%d' % d, int(ncum[d] - (ncum[full_depth - 1] if full_depth else 0)), 4)
+           for d in range(depth_stop, depth + 1)}
+    pos = mpu_points(4096, oc_l.batch_size, 21)
+    cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self        # mpu.py:128 hard-codes .cuda(); no GPU here
+    try:
+        out = RMPU.NeuralMPU(full_depth, depth_stop, depth)(pos, reg, oc_l)
+    finally:
+        torch.Tensor.cuda = cuda
+    save('g_mpu', {'split_small': split, 'split_large': sl, 'pos': pos,
+                   'cfg': (full_depth, depth_stop, depth),
+                   'sdf': {d: v[0].clone() for d, v in out.items()},
+                   'mask': {d: v[1].clone() for d, v in out.items()}})
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['octree_graph', 'modules', 'dense', 'unet', 'sample_loop', 'vae']
+    which = sys.argv[1:] or ['octree_graph', 'modules', 'dense', 'unet', 'sample_loop', 'vae', 'mpu']
     for w in which:
         globals()['g_' + w]()

@@ -393,6 +393,63 @@ def test_vae_decoder(golden):
     assert torch.equal(out2['octree_out'].nnum[:7], G['grow']['nnum'])
 
 
+@pytest.mark.gpu
+def test_neural_mpu_golden(golden):
+    """ofx_mpu_eval against the reference's own NeuralMPU outputs (g_mpu.pt): mask bit-exact, sdf to 1e-4."""
+    from octfusion_amd.mpu import NeuralMPU
+    from octfusion_amd.octree import split2octree_large
+    G = golden('g_mpu')
+    oc, _ = tiny(G['split_small'])
+    oc_l = split2octree_large(oc, G['split_large'].to(dev()), 4)
+    fd, ds, dp = G['cfg']
+    ncum = torch.cumsum(oc_l.nnum, 0)
+    reg = {d: C.rand_input('mpu_code_%d' % d, int(ncum[d] - (ncum[fd - 1] if fd else 0)), 4).to(dev())
+           for d in range(ds, dp + 1)}
+    out = NeuralMPU(fd, ds, dp)(G['pos'].to(dev()), reg, oc_l)
+    for d in range(ds, dp + 1):
+        assert torch.equal(out[d][1].cpu(), G['mask'][d])
+        torch.testing.assert_close(out[d][0].cpu(), G['sdf'][d], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_neural_mpu_shell_vs_oracle_and_grid():
+    """Shell-6 tree, batch 2: random + lattice-aligned + out-of-cube points against oracle/mpu.py; then the
+    in-kernel lattice sweep (calc_sdf) must equal evaluating the same lattice as explicit points, bit for bit."""
+    from oracle import mpu as OMPU
+    from oracle import sampler as OS
+    from octfusion_amd import mpu as M
+    from octfusion_amd.octree import split2octree_small
+    split = C.shell6_split(2, jitter=True)
+    oc = split2octree_small(split.to(dev()), 6, 4)
+    oc_o = OS.split2octree_small(split, 6, 4)
+    assert torch.equal(oc.nnum[:7], oc_o.nnum[:7])
+    fd, dp = 4, 6
+    rows = int(oc.nnum[fd:dp + 1].sum())
+    reg = C.rand_input('mpu_shell_code', rows, 4)
+    g = torch.Generator().manual_seed(5)
+    n = 20000
+    pos = torch.cat([torch.rand(n, 3, generator=g) * 2.2 - 1.1, torch.randint(0, 2, (n, 1), generator=g).float()], 1)
+    pos[:2000, :3] = torch.randint(0, 129, (2000, 3), generator=g).float() / 64 - 1
+    sdf, mask = M.mpu_eval(oc, fd, dp, pos.to(dev()), reg.to(dev()))
+    want, wmask = OMPU.linear_pred(pos, oc_o, reg, fd, dp)
+    assert torch.equal(mask.cpu(), wmask)
+    torch.testing.assert_close(sdf.cpu(), want, rtol=1e-4, atol=1e-5)
+    assert int(mask.sum()) > 100                      # the shell is actually hit
+    # lattice sweep == explicit points
+    field = M.MpuField(fd, dp, reg.to(dev()), oc)
+    size = 48
+    grid = M.calc_sdf(field, batch_size=2, size=size, bbmin=-0.9, bbmax=0.9)
+    generic = M.calc_sdf(lambda p: field(p), batch_size=2, size=size, max_batch=30000, bbmin=-0.9, bbmax=0.9)
+    assert grid.shape == (2, size, size, size)
+    assert torch.equal(grid, generic)
+    # and the lattice coordinates follow numpy's fp32 arithmetic (util_dualoctree.py:102-103)
+    import numpy as np
+    ax = np.arange(size, dtype=np.float32) * ((0.9 - -0.9) / size) + -0.9
+    pts = torch.tensor(np.stack(np.meshgrid(ax, ax, ax, indexing='ij'), -1).reshape(-1, 3))
+    pts = torch.cat([pts, torch.ones(pts.shape[0], 1)], 1)
+    assert torch.equal(field(pts.to(dev())), grid[1].reshape(-1))
+
+
 def _fake_net(shape, device):
     A = torch.linspace(-0.5, 0.5, shape[1]).to(device)
 

@@ -261,3 +261,24 @@ def test_vae_decoder(golden):
     for d in (4, 5, 6):
         torch.testing.assert_close(logits2[d], G['grow']['logits'][d], rtol=2e-4, atol=2e-5)
         assert tuple(regs2[d].shape) == G['grow']['reg_shapes'][d]
+
+
+def mpu_case(G):
+    oc, _ = tiny(G['split_small'])
+    oc_l = OS.split2octree_large(oc, G['split_large'], 4)
+    fd, ds, dp = G['cfg']
+    ncum = torch.cumsum(oc_l.nnum, 0)
+    reg = {d: C.rand_input('mpu_code_%d' % d, int(ncum[d] - (ncum[fd - 1] if fd else 0)), 4)
+           for d in range(ds, dp + 1)}
+    return oc_l, reg, (fd, ds, dp)
+
+
+def test_neural_mpu(golden):
+    """oracle/mpu.py against the reference's own mpu.py outputs (tests/golden/g_mpu.pt)."""
+    from oracle import mpu as OMPU
+    G = golden('g_mpu')
+    oc_l, reg, (fd, ds, dp) = mpu_case(G)
+    out = OMPU.neural_mpu(G['pos'], reg, oc_l, fd, ds, dp)
+    for d in range(ds, dp + 1):
+        assert torch.equal(out[d][1], G['mask'][d])
+        torch.testing.assert_close(out[d][0], G['sdf'][d], rtol=1e-4, atol=1e-5)

@@ -1,0 +1,77 @@
+"""On-disk formats of the reference, read and written without the reference.
+
+* diffusion checkpoints `df_<label>.pth` (models/octfusion_model_union.py:501-545):
+  {'df_unet_lr', 'ema_df_unet_lr', ['df_unet_hr', 'ema_df_unet_hr'], 'opt', 'global_step'};
+* VAE checkpoints (models/model_utils.py:18-28): a state_dict, or {'autoencoder': sd}, or a
+  '.solver.tar' file holding {'model_dict': sd};
+* sample files written by tools/gen_split.py:46-54 and read by datasets/dualoctree_snet.py:137-151:
+  `split_small.pth` = tensor [8, S, S, S] (batch dim squeezed), `split_large.pth` = tensor [nnum6, 8].
+State-dict key names / shapes of octfusion_amd's modules equal the reference's (tests/test_gpu_parity.py), so
+`load_state_dict(strict=True)` is the whole conversion.
+"""
+import os
+
+import torch
+
+
+def _read(ckpt):
+    if isinstance(ckpt, (str, os.PathLike)):
+        return torch.load(ckpt, map_location='cpu', weights_only=False)
+    return ckpt
+
+
+def load_ckpt(ckpt, df, ema_df=None, load_options=('unet_lr', 'unet_hr')):
+    """octfusion_model_union.py:525-545 without the optimizer branch.  df / ema_df: union UNet3DModel
+    instances (ema_df may be None or df itself at inference).  Returns the checkpoint's global_step."""
+    sd = _read(ckpt)
+    for name in ('unet_lr', 'unet_hr'):
+        if name in load_options and 'df_' + name in sd:
+            getattr(df, name).load_state_dict(sd['df_' + name], strict=True)
+            if ema_df is not None:
+                getattr(ema_df, name).load_state_dict(sd['ema_df_' + name], strict=True)
+    return sd.get('global_step')
+
+
+def save_ckpt(path, df, ema_df, global_step, stage_flag='hr', opt_state=None):
+    """octfusion_model_union.py:501-523 (file layout only; rotation of old files is the trainer's business)."""
+    sd = {'df_unet_lr': df.unet_lr.state_dict(), 'ema_df_unet_lr': ema_df.unet_lr.state_dict(),
+          'opt': opt_state if opt_state is not None else {}, 'global_step': global_step}
+    if stage_flag == 'hr':
+        sd['df_unet_hr'] = df.unet_hr.state_dict()
+        sd['ema_df_unet_hr'] = ema_df.unet_hr.state_dict()
+    torch.save(sd, path)
+
+
+def vae_state_dict(ckpt):
+    """models/model_utils.py:18-28: unwrap the three layouts a GraphVAE checkpoint comes in."""
+    sd = _read(ckpt)
+    if isinstance(ckpt, (str, os.PathLike)) and str(ckpt).endswith('.solver.tar'):
+        sd = sd['model_dict']
+    if 'autoencoder' in sd:
+        sd = sd['autoencoder']
+    return sd
+
+
+def load_vae(ckpt, vae):
+    vae.load_state_dict(vae_state_dict(ckpt), strict=True)
+    return vae.eval()
+
+
+def read_splits(sample_dir, device):
+    """A sample directory of the reference's dataset (dualoctree_snet.py:137-151) -> (split_small [1,8,S,S,S],
+    split_large [nnum6, 8] or None) on `device`."""
+    small = torch.load(os.path.join(sample_dir, 'split_small.pth'), map_location='cpu', weights_only=False)
+    if small.dim() == 4:
+        small = small.unsqueeze(0)                  # gen_split.py:52 squeezes the batch dim
+    p = os.path.join(sample_dir, 'split_large.pth')
+    large = torch.load(p, map_location='cpu', weights_only=False) if os.path.exists(p) else None
+    return small.to(device), (large.to(device) if large is not None else None)
+
+
+def write_splits(sample_dir, octree, full_depth=4, small_depth=6):
+    """tools/gen_split.py:50-54 for one shape (octree.batch_size == 1)."""
+    from .octree import octree2split_large, octree2split_small
+    os.makedirs(sample_dir, exist_ok=True)
+    torch.save(octree2split_small(octree, full_depth).squeeze(0).cpu(), os.path.join(sample_dir, 'split_small.pth'))
+    if octree.depth > small_depth:
+        torch.save(octree2split_large(octree, small_depth).cpu(), os.path.join(sample_dir, 'split_large.pth'))

@@ -155,3 +155,26 @@ def split2octree_large(octree, split, small_depth):
     out.octree_grow(small_depth + 2)
     out.depth += 1
     return out
+
+
+def _child_occupancy(octree, depth):
+    """[nnum[depth], 8] fp32 in {0, 1}: child j of node i (at depth+1) is non-empty; rows of empty nodes are 0
+    (ocnn.nn.octree_pad of the reshaped nempty mask, util_dualoctree.py:201-204 / 215-218)."""
+    nz = (octree.children[depth + 1] >= 0).reshape(-1, 8).float()
+    out = torch.zeros(int(octree.nnum[depth]), 8, dtype=torch.float32, device=nz.device)
+    out[octree.nempty_mask(depth)] = nz
+    return out
+
+
+def octree2split_small(octree, full_depth):
+    """utils/util_dualoctree.py:199-211 (inverse of split2octree_small; the diffusion stage-1 data format):
+    -> [B, 8, S, S, S] in {-1, +1}."""
+    from . import ops
+    occ = _child_occupancy(octree, full_depth)
+    return 2 * ops.octree2voxel_cf(occ, octree.batch_size, full_depth) - 1
+
+
+def octree2split_large(octree, small_depth):
+    """utils/util_dualoctree.py:213-223 (inverse of split2octree_large; the stage-2 data format):
+    -> [nnum[small_depth], 8] in {-1, +1}."""
+    return 2 * _child_occupancy(octree, small_depth) - 1

@@ -110,3 +110,20 @@ def split2octree_large(octree, split, small_depth):
     out.octree_grow(small_depth + 2)
     out.depth += 1
     return out
+
+
+def octree2split_small(octree, full_depth):
+    """util_dualoctree.py:199-211: [B, 8, S, S, S] in {-1, +1}; channel j of cell (x, y, z) = child j of that
+    depth-full_depth node is non-empty."""
+    from .octree import octree2voxel, octree_pad
+    nz = (octree.children[full_depth + 1] >= 0).reshape(-1, 8)
+    pad = octree_pad(nz, octree, full_depth)
+    vox = octree2voxel(pad, octree, full_depth).permute(0, 4, 1, 2, 3).contiguous()
+    return 2 * vox.float() - 1
+
+
+def octree2split_large(octree, small_depth):
+    """util_dualoctree.py:213-223: [nnum[small_depth], 8] in {-1, +1}."""
+    from .octree import octree_pad
+    nz = (octree.children[small_depth + 1] >= 0).reshape(-1, 8)
+    return 2 * octree_pad(nz, octree, small_depth).float() - 1

@@ -450,6 +450,63 @@ def test_neural_mpu_shell_vs_oracle_and_grid():
     assert torch.equal(field(pts.to(dev())), grid[1].reshape(-1))
 
 
+def test_split_formats_roundtrip():
+    """octree2split_small / _large on device == oracle, and octree -> splits -> octree is the identity
+    (util_dualoctree.py:199-273); also through the on-disk sample format (gen_split.py:50-54)."""
+    import tempfile
+    from oracle import sampler as OS
+    from octfusion_amd import checkpoint as CK
+    from octfusion_amd.octree import (split2octree_small, split2octree_large, octree2split_small,
+                                      octree2split_large)
+    split = C.shell6_split(1, jitter=True)
+    oc6 = split2octree_small(split.to(dev()), 6, 4)
+    sl = C.random_split_large(int(oc6.nnum[6]), 3, p=0.4)
+    oc8 = split2octree_large(oc6, sl.to(dev()), 6)
+    o8 = OS.split2octree_large(OS.split2octree_small(split, 6, 4), sl, 6)
+    ss, sL = octree2split_small(oc8, 4), octree2split_large(oc8, 6)
+    assert torch.equal(ss.cpu(), OS.octree2split_small(o8, 4))
+    assert torch.equal(sL.cpu(), OS.octree2split_large(o8, 6))
+    with tempfile.TemporaryDirectory() as tmp:
+        CK.write_splits(tmp, oc8)
+        a, b = CK.read_splits(tmp, dev())
+    back = split2octree_large(split2octree_small(a, 6, 4), b, 6)
+    for d in range(9):
+        assert torch.equal(back.keys[d], oc8.keys[d])
+        if d < 8:
+            assert torch.equal(back.children[d], oc8.children[d])
+
+
+def test_checkpoint_layout_roundtrip(golden):
+    """df_<label>.pth layout (octfusion_model_union.py:501-545): a file written with the reference's keys loads
+    strict=True into a fresh model and reproduces the golden output."""
+    import tempfile
+    import os
+    from octfusion_amd import checkpoint as CK
+    from octfusion_amd import graph_unet_union as U
+    G = golden('g_unet')
+    oc, doc = small(G['split_small'])
+    r = G['uncond']
+    cfg = union_cfg(r['num_classes'])
+    sd = C.fill_state_dict(r['keys'])
+    lr = {k[len('unet_lr.'):]: v for k, v in sd.items() if k.startswith('unet_lr.')}
+    hr = {k[len('unet_hr.'):]: v for k, v in sd.items() if k.startswith('unet_hr.')}
+    assert lr and hr and len(lr) + len(hr) == len(sd)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'df_steps-latest.pth')
+        torch.save({'df_unet_lr': lr, 'ema_df_unet_lr': lr, 'df_unet_hr': hr, 'ema_df_unet_hr': hr,
+                    'opt': {}, 'global_step': 1234}, path)
+        net = U.UNet3DModel(**cfg).to(dev()).eval()
+        assert CK.load_ckpt(path, net, net) == 1234
+        path2 = os.path.join(tmp, 'df_steps-2.pth')
+        CK.save_ckpt(path2, net, net, 7)
+        again = torch.load(path2, map_location='cpu', weights_only=False)
+    assert set(again) == {'df_unet_lr', 'ema_df_unet_lr', 'df_unet_hr', 'ema_df_unet_hr', 'opt', 'global_step'}
+    assert list(again['df_unet_hr']) == list(hr) and all(torch.equal(again['df_unet_hr'][k].cpu(), hr[k]) for k in hr)
+    y = net(unet_type='hr', x=r['x'].to(dev()), doctree=doc, unet_lr=net.unet_lr, timesteps=r['t'].to(dev()),
+            x_self_cond=None, label=None)
+    close(y, r['out'], 1e-3)
+
+
 def _fake_net(shape, device):
     A = torch.linspace(-0.5, 0.5, shape[1]).to(device)
 

@@ -282,3 +282,21 @@ def test_neural_mpu(golden):
     for d in range(ds, dp + 1):
         assert torch.equal(out[d][1], G['mask'][d])
         torch.testing.assert_close(out[d][0], G['sdf'][d], rtol=1e-4, atol=1e-5)
+
+
+def test_split_roundtrip_oracle():
+    """octree -> (split_small, split_large) -> octree is the identity on keys (util_dualoctree.py:199-273)."""
+    oc6 = OS.split2octree_small(C.shell6_split(2, jitter=True), 6, 4)
+    x, y, z, b = oc6.xyzb(6)
+    sl = C.random_split_large(int(oc6.nnum[6]), 3, p=0.4)
+    oc8 = OS.split2octree_large(oc6, sl, 6)
+    ss = OS.octree2split_small(oc8, 4)
+    assert ss.shape == (2, 8, 16, 16, 16) and set(ss.unique().tolist()) <= {-1.0, 1.0}
+    back6 = OS.split2octree_small(ss, 6, 4)
+    back8 = OS.split2octree_large(back6, OS.octree2split_large(oc8, 6), 6)
+    for d in range(9):
+        assert torch.equal(back8.keys[d], oc8.keys[d])
+        if d < 8:
+            assert torch.equal(back8.children[d], oc8.children[d])
+    # split_large of a grown tree marks exactly the children that were grown
+    assert torch.equal(OS.octree2split_large(oc8, 6) > 0, (sl > 0) & ((sl > 0).any(1, keepdim=True)))

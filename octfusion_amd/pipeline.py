@@ -9,12 +9,13 @@ for 3), on device, for a whole batch of independent shapes.
     feat : (3-stage) DDIM on [N8, 3] latent codes
     ->     GraphVAE.decode_code (grows 6 -> 8 on device when 2-stage)
 
-Mesh extraction (NeuralMPU sweep + marching cubes, octfusion_model_union.py:400-468) is the
-next row and not done here.
+    sdf  : NeuralMPU sweep of the decoded field on the resolution^3 lattice in [-sdf_scale, sdf_scale]^3
+           (get_sdfs, octfusion_model_union.py:425-433) -- one kernel launch per shape.
+Marching cubes (skimage on the host, octfusion_model_union.py:435-468) is outside the device path.
 """
 import torch
 
-from . import sampler
+from . import mpu, sampler
 from .dual_octree import DualOctree
 from .octree import split2octree_large, split2octree_small
 
@@ -32,9 +33,11 @@ class CascadeSampler:
         self.depths = list(cfg['input_depth'])
 
     @torch.no_grad()
-    def sample(self, batch_size, ddim_steps=200, label=None, split_small=None, noises=None):
+    def sample(self, batch_size, ddim_steps=200, label=None, split_small=None, noises=None, sdf_resolution=None,
+               sdf_scale=0.9):
         """Returns a dict with the per-stage results.  `noises` (optional) = dict of explicit
-        init / step noise tensors per stage for reproducible runs."""
+        init / step noise tensors per stage for reproducible runs.  sdf_resolution (e.g. 256) adds
+        out['sdfs'] [B, R, R, R] (needs the VAE)."""
         noises = noises or {}
         out = {}
         S = 1 << self.full_depth
@@ -70,4 +73,7 @@ class CascadeSampler:
         out['doctree'] = doctree
         if self.vae is not None:
             out['decoded'] = self.vae.decode_code(x, doctree)
+            if sdf_resolution:
+                out['sdfs'] = mpu.calc_sdf(out['decoded']['neural_mpu'], batch_size, size=sdf_resolution,
+                                           bbmin=-sdf_scale, bbmax=sdf_scale)
         return out

@@ -549,8 +549,15 @@ def test_cascade_two_stage_runs():
     vae.load_state_dict(synthetic.random_state_dict(vae))
     vae = vae.to(dev()).eval()
     cs = pipeline.CascadeSampler(net, cfg, vae)
-    out = cs.sample(1, ddim_steps=3, split_small=synthetic.shell6_split(1, jitter=False).to(dev()))
+    out = cs.sample(1, ddim_steps=3, split_small=synthetic.shell6_split(1, jitter=False).to(dev()), sdf_resolution=64)
     assert out['octree_small'].nnum.tolist() == [1, 8, 64, 512, 4096, 4672, 20032]
+    # SDF sweep of the decoded field (get_sdfs): lattice result == the field evaluated at explicit points
+    sdfs = out['sdfs']
+    assert tuple(sdfs.shape) == (1, 64, 64, 64) and bool(torch.isfinite(sdfs).all())
+    q = torch.tensor([[5, 17, 40], [63, 0, 31]])
+    pts = torch.cat([q.float() * (1.8 / 64) - 0.9, torch.zeros(2, 1)], 1).to(dev())
+    want = out['decoded']['neural_mpu'](pts)
+    torch.testing.assert_close(sdfs[0, q[:, 0], q[:, 1], q[:, 2]], want, rtol=1e-6, atol=1e-7)
     assert tuple(out['hr'].shape) == (25712, 3) and bool(torch.isfinite(out['hr']).all())
     dec = out['decoded']
     assert set(dec['logits']) == {6, 7, 8} and dec['octree_out'].depth == 8

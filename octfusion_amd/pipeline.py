@@ -34,7 +34,7 @@ class CascadeSampler:
 
     @torch.no_grad()
     def sample(self, batch_size, ddim_steps=200, label=None, split_small=None, noises=None, sdf_resolution=None,
-               sdf_scale=0.9):
+               sdf_scale=0.9, use_graph=False):
         """Returns a dict with the per-stage results.  `noises` (optional) = dict of explicit
         init / step noise tensors per stage for reproducible runs.  sdf_resolution (e.g. 256) adds
         out['sdfs'] [B, R, R, R] (needs the VAE)."""
@@ -46,7 +46,7 @@ class CascadeSampler:
             split_small = sampler.sample_loop(
                 self.net, (batch_size, self.cfg['input_channels'][0], S, S, S), batch_size, ddim_steps, 'lr',
                 self.df_type[0], self.device, label=label, truncated_index=sampler.TRUNCATED_TIME,
-                init_noise=n.get('init'), step_noise=n.get('steps'))
+                init_noise=n.get('init'), step_noise=n.get('steps'), use_graph=use_graph)
         out['split_small'] = split_small
         octree = split2octree_small(split_small, self.depths[1], self.full_depth)
         out['octree_small'] = octree
@@ -56,7 +56,7 @@ class CascadeSampler:
         n = noises.get('hr', {})
         x = sampler.sample_loop(self.net, (doctree.total_num, self.cfg['input_channels'][1]), batch_size, ddim_steps,
                                 'hr', self.df_type[1], self.device, doctree=doctree, unet_lr=self.net.unet_lr,
-                                label=label, init_noise=n.get('init'), step_noise=n.get('steps'))
+                                label=label, init_noise=n.get('init'), step_noise=n.get('steps'), use_graph=use_graph)
         out['hr'] = x
         if len(self.stages) >= 3:
             nn6 = int(octree.nnum[self.depths[1]])
@@ -68,7 +68,7 @@ class CascadeSampler:
             x = sampler.sample_loop(self.net, (doctree.total_num, self.cfg['input_channels'][2]), batch_size,
                                     ddim_steps, 'feature', self.df_type[2], self.device, doctree=doctree,
                                     unet_lr=self.net.unet_hr, label=label, init_noise=n.get('init'),
-                                    step_noise=n.get('steps'))
+                                    step_noise=n.get('steps'), use_graph=use_graph)
             out['feature'] = x
         out['doctree'] = doctree
         if self.vae is not None:

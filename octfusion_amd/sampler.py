@@ -50,34 +50,86 @@ def ddim_eps_step(x, eps, t, t_next):
 
 
 @torch.no_grad()
+def _step(net, x, noise_cond, unet_type, df_type, doctree, unet_lr, label, x_self, coef, noise, do_sign, x0_out):
+    """One denoising step on device tensors only (what gets captured into a hipGraph): U-Net forward + update.
+    Returns the tensor the next step receives as x_self_cond."""
+    out = net(unet_type=unet_type, x=x, doctree=doctree, timesteps=noise_cond, unet_lr=unet_lr,
+              x_self_cond=x_self, label=label)
+    if do_sign:
+        out = out.sign_()
+    out = out.contiguous()
+    if df_type == 'x0':
+        ops.ddim_x0_update(x, out, noise, coef)
+        return out
+    if df_type == 'eps':
+        # the reference also keeps x_start = (x - eps*sigma)/alpha and passes it on as x_self_cond
+        # (octfusion_model_union.py:349, :320); the hr / feature nets ignore it, so it is only
+        # materialised for nets that declare they want it.
+        ops.ddim_eps_update(x, out, coef, x0_out)
+        return x0_out
+    raise ValueError(df_type)
+
+
 def sample_loop(net, shape, batch_size, ddim_steps, unet_type, df_type, device, doctree=None, unet_lr=None,
-                label=None, truncated_index=0.0, init_noise=None, step_noise=None):
+                label=None, truncated_index=0.0, init_noise=None, step_noise=None, use_graph=False):
     """Run `ddim_steps` denoising steps; `net` is a graph_unet_union.UNet3DModel (or any callable with
-    its keyword interface).  Noise comes from torch's device RNG unless given explicitly."""
+    its keyword interface).  Noise comes from torch's device RNG unless given explicitly.
+
+    use_graph: every shape is static across the steps of a stage (the doctree is fixed), so after one eager
+    step the step is captured into a hipGraph per regime (sign / noise / first-step flags) and replayed with
+    x, log-SNR, coefficients, noise and the self-conditioning tensor in static device buffers."""
     x = torch.randn(shape, device=device) if init_noise is None else init_noise.to(device).clone()
     x = x.contiguous()
+    wants_sc = getattr(net, 'wants_self_cond', True)
     x_start = None
+    graphs = {}
+    st = {}
+    if use_graph:
+        st['cond'] = torch.zeros(batch_size, dtype=torch.float32, device=device)
+        st['self'] = torch.zeros_like(x)
+        st['noise'] = torch.zeros_like(x)
     for i, (t, t_next) in enumerate(sampling_times(ddim_steps)):
         noise_cond = beta_linear_log_snr(t).float().expand(batch_size).contiguous().to(device)
-        out = net(unet_type=unet_type, x=x, doctree=doctree, timesteps=noise_cond, unet_lr=unet_lr,
-                  x_self_cond=x_start, label=label)
-        if float(t) < truncated_index and unet_type == 'lr':
-            out = out.sign_()
-        out = out.contiguous()
+        do_sign = float(t) < truncated_index and unet_type == 'lr'
         if df_type == 'x0':
-            x_start = out
             coef = x0_coef(t, t_next, truncated_index).to(device)
             noise = None
             if float(coef[3]) != 0.0:
                 noise = torch.randn_like(x) if step_noise is None else step_noise[i].to(device)
-            ops.ddim_x0_update(x, out, noise, coef)
-        elif df_type == 'eps':
-            # the reference also keeps x_start = (x - eps*sigma)/alpha and passes it on as x_self_cond
-            # (octfusion_model_union.py:349, :320); the hr / feature nets ignore it, so it is only
-            # materialised for nets that declare they want it.
-            x0_out = torch.empty_like(x) if getattr(net, 'wants_self_cond', True) else None
-            ops.ddim_eps_update(x, out, eps_coef(t, t_next).to(device), x0_out)
-            x_start = x0_out
         else:
-            raise ValueError(df_type)
+            coef = eps_coef(t, t_next).to(device)
+            noise = None
+        if not use_graph or i == 0:
+            x0_out = torch.empty_like(x) if (df_type == 'eps' and wants_sc) else None
+            x_start = _step(net, x, noise_cond, unet_type, df_type, doctree, unet_lr, label, x_start, coef, noise,
+                            do_sign, x0_out)
+            continue
+        # ---- hipGraph replay -------------------------------------------------------------------------
+        key = (do_sign, noise is not None, x_start is not None)
+        st['cond'].copy_(noise_cond)
+        if x_start is not None and x_start is not st['self']:
+            st['self'].copy_(x_start)
+        if noise is not None:
+            st['noise'].copy_(noise)
+        if key not in graphs:
+            c = coef.clone()
+            x0_buf = torch.empty_like(x) if (df_type == 'eps' and wants_sc) else None
+            args = (net, x, st['cond'], unet_type, df_type, doctree, unet_lr, label,
+                    st['self'] if key[2] else None, c, st['noise'] if key[1] else None, do_sign, x0_buf)
+            g = torch.cuda.CUDAGraph()
+            keep = x.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                _step(*args)                           # warm-up of this regime outside the capture
+            torch.cuda.current_stream().wait_stream(side)
+            x.copy_(keep)
+            with torch.cuda.graph(g):
+                res = _step(*args)
+            x.copy_(keep)
+            graphs[key] = (g, c, res)
+        g, c, res = graphs[key]
+        c.copy_(coef)
+        g.replay()
+        x_start = res
     return x

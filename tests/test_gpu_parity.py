@@ -535,6 +535,33 @@ def test_sample_loop(golden, name, unet_type, df_type):
     close(y, r['out'], 2e-5)
 
 
+def test_sample_loop_hipgraph_replay(golden):
+    """use_graph=True (one eager step, then hipGraph replay per regime) gives the eager result: bit-equal for
+    the pure-kernel fake net on the x0 branch (sign + noise + self-conditioning regimes), 1e-5 for a real
+    union net on the eps branch (fp64 atomics in the fused statistics may reorder)."""
+    from octfusion_amd import sampler, graph_unet_union as U
+    r = golden('g_sample_loop')['x0']
+    shape = tuple(r['shape'])
+    torch.manual_seed(r['seed'])
+    init = torch.randn(shape)
+    steps = [torch.randn(shape) for _ in range(r['steps'])]
+    kw = dict(truncated_index=r.get('trunc', 0.0), init_noise=init, step_noise=steps)
+    a = sampler.sample_loop(_fake_net(shape, dev()), shape, r['B'], r['steps'], 'lr', 'x0', dev(), **kw)
+    b = sampler.sample_loop(_fake_net(shape, dev()), shape, r['B'], r['steps'], 'lr', 'x0', dev(), use_graph=True, **kw)
+    assert torch.equal(a, b)
+    close(b, r['out'], 2e-5)
+    G = golden('g_unet')
+    oc, doc = small(G['split_small'])
+    net = load(U.UNet3DModel(**union_cfg(None)), G['uncond']['keys'])
+    shp = (doc.total_num, 3)
+    init = torch.randn(shp)
+    ya = sampler.sample_loop(net, shp, doc.batch_size, 6, 'hr', 'eps', dev(), doctree=doc, unet_lr=net.unet_lr,
+                             init_noise=init)
+    yb = sampler.sample_loop(net, shp, doc.batch_size, 6, 'hr', 'eps', dev(), doctree=doc, unet_lr=net.unet_lr,
+                             init_noise=init, use_graph=True)
+    close(yb, ya, 1e-5)
+
+
 def test_cascade_two_stage_runs():
     """lr -> octree -> hr -> VAE decode, end to end on device with shrunken nets (shape / sanity checks;
     stage-wise numerics are pinned by the other tests)."""

@@ -1361,6 +1361,7 @@ extern "C" int ofx_pack_conv3d(const float* W, int cin, int cout, float* Wp, voi
 extern "C" int ofx_gemm_f32(const float* A, int64_t lda, const int32_t* a_rows, int64_t M, int64_t K, const float* Wp,
                             int64_t Kp, int64_t N, const float* bias, const float* res, int64_t ldr, float* out,
                             int64_t ldc, const int32_t* out_rows, void* ws, size_t ws_bytes, void* stream) {
+  if (M == 0 && K >= 1 && N >= 1) return OFX_OK;          // empty input: nothing to do (out may be a null pointer)
   if (M < 0 || K < 1 || N < 1 || !Wp || !out || (M > 0 && !A) || Kp != pad32(K) || lda < K || ldc < N ||
       (res && ldr < N) || ((uintptr_t)Wp & 15))
     return OFX_EINVAL;
@@ -1440,6 +1441,7 @@ extern "C" int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n
                                  const float* emb, int64_t lde, const int32_t* batch_id, const float* res, int64_t ldr,
                                  float* out, int64_t ldc, double* stats, int64_t stats_ld, void* ws, size_t ws_bytes,
                                  void* stream) {
+  if (n_nodes == 0 && cin >= 1 && cout >= 1) return OFX_OK;      // empty graph level: nothing to do
   GemmArgs g = {};
   int rc = gather_common(g, x, ldx, cin, 7, n_nodes, nbr, seg_ptr, col, Wp, Kp, cout, bias, emb, lde, batch_id, res,
                          ldr, out, ldc);
@@ -1477,6 +1479,7 @@ extern "C" int ofx_gridconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_
                                 const float* bias, const float* emb, int64_t lde, const int32_t* batch_id,
                                 const float* res, int64_t ldr, float* out, int64_t ldc, void* ws, size_t ws_bytes,
                                 void* stream) {
+  if (n_out == 0 && cin >= 1 && cout >= 1) return OFX_OK;
   GemmArgs g = {};
   const int64_t Kp = ofx_conv3d_packed_k(cin);
   int rc = gather_common(g, x, ldx, cin, 27, n_out, nbr27 ? nbr27 : nbr27_ext, nullptr, nullptr, Wp, Kp, cout, bias,

@@ -248,6 +248,56 @@ def test_graphconv_wide_vs_oracle():
         close(m(x.to(dev()), doc, d, emb=emb.to(dev()), res=res.to(dev())), ref2)
 
 
+def test_fused_statistics_and_edge_shapes():
+    """(a) GroupNorm sums produced by the GraphConv epilogue (two-stage partials + mixed-batch waves + col path for
+    Cin % 32 != 0) equal the stand-alone gn_stats pass on the same output, on a ragged batch of 5 whose element
+    boundaries fall inside tiles and waves; (b) widths that are not multiples of 4 / 32 and M = 0, 1 rows."""
+    from octfusion_amd import modules as M, ops
+    from oracle import dual_octree as OD, modules as OM, sampler as OS
+    split = C.random_split_small(5, 3, 41, p=0.4)
+    split[3] = -1.0                                   # an element with nothing below the full layer
+    oc, doc = small(split)
+    o_doc = OD.OracleDualOctree(OS.split2octree_small(split, 5, 3))
+    o_doc.post_processing_for_docnn()
+    for d, cin, cout, nt in [(5, 64, 128, 4), (4, 32, 64, 3), (5, 24, 32, 4), (5, 3, 128, 4)]:
+        m = M.GraphConv(cin, cout, 7, 7, nt)
+        sd = C.fill_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()])
+        m.load_state_dict(sd)
+        m = m.to(dev())
+        N = doc.csr(d)[2]
+        x = C.rand_input('fs%d_%d' % (d, cin), N, cin).to(dev())
+        res = C.rand_input('fsr%d_%d' % (d, cin), N, cout).to(dev())
+        stats = torch.zeros(5 * cout * 2, dtype=torch.float64, device=dev())
+        pw = m._pw.get(m.weights, 'graphconv', cin, nt)
+        seg_ptr, col, _, _ = doc.csr(d)
+        y = ops.graphconv(x, doc.nbr(d), seg_ptr, col, pw, cin, doc.type_frac(d, nt), None, None, doc.batch_id32(d),
+                          res, None, ext=doc.ext(d), stats=stats)
+        ref = OM.graph_conv(x.cpu(), o_doc, d, sd['weights'], None, nt) + res.cpu()
+        close(y, ref)
+        bid = doc.batch_id32(d).long()
+        want = torch.zeros(5, cout, 2, dtype=torch.float64, device=dev())
+        want[:, :, 0].index_add_(0, bid, y.double())
+        want[:, :, 1].index_add_(0, bid, y.double() ** 2)
+        got = stats.view(5, cout, 2)
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        # and the norm that consumes them equals the oracle norm of the same tensor
+        gn = M.DualOctreeGroupNorm(cout).to(dev())
+        setattr(y, ops.STATS_ATTR, stats)
+        wgt, bs = C.rand_input('fsw%d' % cout, 1, cout), C.rand_input('fsb%d' % cout, 1, cout)
+        gn.load_state_dict({'weights': wgt, 'bias': bs})
+        want_n = OM.dual_octree_group_norm(y.cpu(), o_doc, d, wgt, bs, 32)
+        close(gn(y, doc, d), want_n, 1e-4)
+    # (b) odd shapes through the dense contraction
+    for Mrows, K, Ncol in [(0, 64, 32), (1, 32, 5), (127, 96, 66), (129, 40, 130), (300, 7, 1)]:
+        A = torch.randn(Mrows, K)
+        W = torch.randn(K, Ncol)
+        b = torch.randn(Ncol)
+        y = ops.gemm(A.to(dev()), ops.PackedWeight().get(W.to(dev()), 'kn'), bias=b.to(dev()))
+        assert tuple(y.shape) == (Mrows, Ncol)
+        if Mrows:
+            close(y, (A.double() @ W.double() + b.double()).float(), 1e-4)
+
+
 def to_rows(vox, depth):
     from octfusion_amd import ops
     return ops.voxel2octree_cf(vox.to(dev()).contiguous(), depth)

@@ -112,6 +112,36 @@ class GraphVAE(nn.Module):
         return octree_out
 
     @torch.no_grad()
+    def octree_encoder_step(self, data, doctree):
+        """graph_vae.py:134-160 with the input feature passed in (the reference takes it from the ocnn octree,
+        graph_vae.py:131-132): data [N_depth, channel_in] -> {d: features} down to depth_stop."""
+        depth, ds = self.depth, self.depth_stop
+        convs = {depth: data}
+        for i, d in enumerate(range(depth, ds - 1, -1)):
+            convd = convs[d]
+            if d == depth:
+                convd = self.conv1(convd, doctree, d)
+            convd = self.encoder[i](convd, doctree, d)
+            convs[d] = convd
+            if d > ds:
+                convs[d - 1] = self.downsample[i](convd, doctree, d - 1)
+        convs[ds] = self.encoder_norm_out(convs[ds], doctree, ds, act='gelu')
+        return convs
+
+    @torch.no_grad()
+    def encode(self, data, doctree, noise=None, sample=True):
+        """graph_vae.py:162-170 / 291-298: KL_conv -> DiagonalGaussianDistribution (distributions.py:24-37).
+        Returns (code [N, embed_dim], mean, logvar); code = mean + exp(logvar / 2) * noise, or the mean."""
+        h = self.octree_encoder_step(data, doctree)[self.depth_stop]
+        mean, logvar = torch.chunk(self.KL_conv(h), 2, dim=1)
+        logvar = torch.clamp(logvar, -30.0, 20.0)
+        if not sample:
+            return mean.contiguous(), mean, logvar
+        if noise is None:
+            noise = torch.randn_like(mean)
+        return (mean + torch.exp(0.5 * logvar) * noise).contiguous(), mean, logvar
+
+    @torch.no_grad()
     def octree_decoder(self, code, doctree_out, update_octree=False):
         ds = self.depth_stop
         x = self.post_KL_conv(code)

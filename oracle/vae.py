@@ -83,3 +83,34 @@ def decode_code(sd, cfg, code, doctree_in, update_octree=True):
     else:
         doctree_out = doctree_in
     return octree_decoder(sd, cfg, code, doctree_out, update_octree)
+
+
+def vae_downsample(x, doctree, d, sd):
+    """dualoctree_networks/modules.py:39-68; `d` = depth of the OUTPUT."""
+    out = M.pool_rearrange(x, doctree, d + 1, sd['downsample.weights'])
+    if 'conv1x1.conv.linear.weight' in sd:
+        out = M.conv1x1_gn(out, doctree, d, M._sub(sd, 'conv1x1'), gelu=True)
+    return out
+
+
+def octree_encoder_step(sd, cfg, data, doctree):
+    """graph_vae.py:134-160 with the input feature given; returns {d: features}."""
+    depth, ds = cfg['depth'], cfg['depth_stop']
+    convs = {depth: data}
+    for i, d in enumerate(range(depth, ds - 1, -1)):
+        convd = convs[d]
+        if d == depth:
+            convd = M.graph_conv(convd, doctree, d, sd['conv1.weights'], None, depth - 1)
+        convd = M.graph_resblocks(convd, doctree, d, M._sub(sd, 'encoder.%d' % i), d - 1)
+        convs[d] = convd
+        if d > ds:
+            convs[d - 1] = vae_downsample(convd, doctree, d - 1, M._sub(sd, 'downsample.%d' % i))
+    h = M.dual_octree_group_norm(convs[ds], doctree, ds, sd['encoder_norm_out.weights'], sd['encoder_norm_out.bias'])
+    convs[ds] = F.gelu(h)
+    return convs
+
+
+def encode(sd, cfg, data, doctree):
+    """graph_vae.py:162-170: the KL_conv output [N, 2 * embed_dim] (mean | logvar)."""
+    h = octree_encoder_step(sd, cfg, data, doctree)[cfg['depth_stop']]
+    return h, F.linear(h, sd['KL_conv.linear.weight'], sd['KL_conv.linear.bias'])

@@ -371,6 +371,27 @@ def g_vae():
     save('g_vae', rec)
 
 
+# ---------------------------------------------------------------- G10
+def g_vae_enc():
+    """GraphVAE encoder (octree_encoder_step + KL_conv) on the tiny depth-6 tree with a random input feature
+    (the reference reads it from the ocnn octree: graph_vae.py:131-132; patched to return the tensor)."""
+    from models.networks.dualoctree_networks.graph_vae import GraphVAE
+    split, oc, doc = tiny_doctree()
+    sl = C.random_split_large(int(oc.nnum[4]), 11, p=0.3)
+    oc_l = split2octree_large(oc, sl, 4)
+    doc_l = RD.DualOctree(oc_l)
+    doc_l.post_processing_for_docnn()
+    vae = GraphVAE(**VAE_CFG).eval()
+    ks = load_filled(vae)
+    N6 = doc_l.graph[6]['node_type'].numel()
+    data = C.rand_input('vae_enc_in', N6, 4)
+    vae._get_input_feature = lambda d: data
+    convs = vae.octree_encoder_step(oc_l, doc_l)
+    code = vae.KL_conv(convs[4])
+    save('g_vae_enc', {'split_small': split, 'split_large': sl, 'keys': ks, 'cfg': VAE_CFG,
+                       'h_rows8': convs[4][::8].clone(), 'kl': code.clone()})      # every 8th row of h: small fixture
+
+
 # ---------------------------------------------------------------- G9
 def mpu_points(n, B, seed):
     """Query points: uniform in the cube, plus points on / beyond cell-centre planes and the cube boundary."""
@@ -406,6 +427,6 @@ def g_mpu():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['octree_graph', 'modules', 'dense', 'unet', 'sample_loop', 'vae', 'mpu']
+    which = sys.argv[1:] or ['octree_graph', 'modules', 'dense', 'unet', 'sample_loop', 'vae', 'mpu', 'vae_enc']
     for w in which:
         globals()['g_' + w]()

@@ -557,6 +557,28 @@ def test_checkpoint_layout_roundtrip(golden):
     close(y, r['out'], 1e-3)
 
 
+def test_vae_encoder(golden):
+    """GraphVAE encoder (conv1 -> res-blocks -> VAE GraphDownsample x2 -> norm+GELU -> KL_conv) vs the reference
+    outputs of g_vae_enc.pt; then encode() -> decode_code() runs end to end."""
+    from octfusion_amd.graph_vae import GraphVAE
+    from octfusion_amd.octree import split2octree_large
+    from octfusion_amd.dual_octree import DualOctree
+    G = golden('g_vae_enc')
+    oc, _ = tiny(G['split_small'])
+    doc_l = DualOctree(split2octree_large(oc, G['split_large'].to(dev()), 4))
+    vae = load(GraphVAE(**G['cfg']), G['keys'])
+    data = C.rand_input('vae_enc_in', doc_l.csr(6)[2], 4).to(dev())
+    convs = vae.octree_encoder_step(data, doc_l)
+    close(convs[4][::8], G['h_rows8'], 1e-3)
+    code, mean, logvar = vae.encode(data, doc_l, sample=False)
+    close(torch.cat([mean, logvar], 1), G['kl'].clamp(min=-1e30), 1e-3)
+    noise = torch.randn_like(mean)
+    code2, _, _ = vae.encode(data, doc_l, noise=noise)
+    torch.testing.assert_close(code2, mean + torch.exp(0.5 * logvar) * noise)
+    out = vae.decode_code(code, doc_l, update_octree=False)
+    assert set(out['logits']) == {4, 5, 6} and all(bool(torch.isfinite(v).all()) for v in out['reg_voxs'].values())
+
+
 def _fake_net(shape, device):
     A = torch.linspace(-0.5, 0.5, shape[1]).to(device)
 

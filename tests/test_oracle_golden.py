@@ -300,3 +300,17 @@ def test_split_roundtrip_oracle():
             assert torch.equal(back8.children[d], oc8.children[d])
     # split_large of a grown tree marks exactly the children that were grown
     assert torch.equal(OS.octree2split_large(oc8, 6) > 0, (sl > 0) & ((sl > 0).any(1, keepdim=True)))
+
+
+def test_vae_encoder(golden):
+    from oracle import vae as OV
+    G = golden('g_vae_enc')
+    oc, _ = tiny(G['split_small'])
+    oc_l = OS.split2octree_large(oc, G['split_large'], 4)
+    doc_l = OD.OracleDualOctree(oc_l)
+    doc_l.post_processing_for_docnn()
+    sd = C.fill_state_dict(G['keys'])
+    data = C.rand_input('vae_enc_in', doc_l.graph[6]['node_type'].numel(), 4)
+    h, kl = OV.encode(sd, G['cfg'], data, doc_l)
+    torch.testing.assert_close(h[::8], G['h_rows8'], rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(kl, G['kl'], rtol=2e-4, atol=2e-5)

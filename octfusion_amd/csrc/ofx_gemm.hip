@@ -787,7 +787,11 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int l31 = lane & 31, h = lane >> 5;
-  const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  // A-tile loader mapping: 8 lanes per 128-B row chunk; the two rows of a 16-lane group are 4 apart so their
+  // 64-B LDS writes (80-B row pitch) land on disjoint halves of the 32 banks (consecutive rows overlap by 4
+  // banks: SQ_LDS_BANK_CONFLICT was 33 % of the LDS-active cycles with r0 = tid >> 3)
+  const int c4 = threadIdx.x & 7;
+  const int r0 = ((threadIdx.x >> 4) & 3) + 8 * (threadIdx.x >> 6) + 4 * ((threadIdx.x >> 3) & 1);
 
   const gfp xp = (gfp)sgpr64((uint64_t)(MODE == MODE_DENSE ? g.A : g.x));
   const gfp tfp = (gfp)sgpr64((uint64_t)g.tf);

@@ -762,8 +762,9 @@ template <int MODE, int WM, int WN, int MI, int NI>
 __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
   // LDS carries only the A tile (hi and lo planes, [128][32+8] bf16 each, double buffered = 40 KB).
   // The weight fragments go global(L2) -> registers directly in MFMA operand layout (the packed
-  // [k/8][n][8] planes give every lane one contiguous 16-B read): with B also staged through LDS the
-  // LDS pipe (writes at ~80 B/clk + reads) was ~85 % as busy as the matrix pipe and capped the kernel.
+  // [k/8][n][8] planes give every lane one contiguous 16-B read).  Staging the weight tile through LDS
+  // instead (half the weight loads, twice the LDS fragment reads) was built and measured twice -- before
+  // and after the interleaved pipeline -- and is 0-4 % slower.
   constexpr int BN = WN * NI * 32;
   constexpr int A_BYTES = BM * 80;                      // one A plane (hi or lo)
   constexpr int BUF_BYTES = 2 * A_BYTES;

@@ -233,10 +233,13 @@ def main():
         t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (mfma_peak * 1e12)
         bound = 'hbm' if t_hbm >= t_mfma else 'mfma'
         traffic = None
+        mfma_pmc = None
         tpath = os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get('graphconv_hbm_bytes_per_launch')
+                pj = json.load(open(tpath))
+                traffic = pj.get('graphconv_hbm_bytes_per_launch')
+                mfma_pmc = pj.get('mfma')
             except Exception:
                 traffic = None
         roof = {'kernel': ('gemm_bf16x3_kernel<1,2,2,2,2> (fused GraphConv / 27-tap gridconv: gather -> bf16x3 MFMA, fp32 accumulate)'
@@ -247,6 +250,7 @@ def main():
                 'unit': 'GB/s' if bound == 'hbm' else 'TFLOP/s',
                 'frac': (ach_gbs / HBM_PEAK_GBS) if bound == 'hbm' else (ach_tf / mfma_peak),
                 'traffic': traffic,
+                'mfma_pmc': mfma_pmc,
                 'launches': launches, 'avg_launch_us': 1e3 * t_ms / max(launches, 1),
                 'algorithmic_flops_per_launch': flops / max(launches, 1),
                 'algorithmic_bytes_per_launch': nbytes / max(launches, 1),

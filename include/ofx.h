@@ -134,6 +134,39 @@ int ofx_graph_expand(const int32_t* seg_ptr, int64_t n_nodes, const int32_t* col
 /* nbr[r*7+dir] = the single neighbour of segment (r,dir), -1 if none, -2 if several. */
 int ofx_graph_primary(const int32_t* seg_ptr, const int32_t* col, int64_t n_nodes, int32_t* nbr,
                       void* stream);
+/* Reverse graph for the backward pass of GraphConv (autograd of index_select + scatter_mean,
+ * models/networks/modules.py:205-213): reverse segment (c, dir) lists the forward edges with col == c in
+ * direction dir; rev_row = their rows (sorted), rev_w = 1 / size of the forward segment (row, dir).
+ * rev_cnt doubles as the fill cursor (it is zeroed and rewritten by _fill). */
+int ofx_graph_reverse_count(const int32_t* seg_ptr, const int32_t* col, int64_t n_nodes, int32_t* rev_cnt,
+                            void* stream);
+int ofx_graph_reverse_fill(const int32_t* seg_ptr, const int32_t* col, int64_t n_nodes, const int32_t* rev_ptr,
+                           int32_t* cursor, int32_t* rev_row, float* rev_w, void* stream);
+/* weighted-graph variants of ofx_graph_primary / _multi_flag / _primary_ext: a segment counts as a single plain
+ * source row only if it has one edge of weight exactly 1 */
+int ofx_graph_primary_w(const int32_t* seg_ptr, const int32_t* col, const float* w, int64_t n_nodes, int32_t* nbr,
+                        void* stream);
+int ofx_graph_multi_flag_w(const int32_t* seg_ptr, const float* w, int64_t n_nodes, int32_t* flag, void* stream);
+int ofx_graph_primary_ext_w(const int32_t* seg_ptr, const int32_t* col, const float* w, int64_t n_nodes,
+                            const int32_t* rank, int32_t* nbr_ext, int32_t* multi_seg, void* stream);
+/* Backward of GraphConv (training path; autograd of models/networks/modules.py:194-220).
+ * _bwd_data: dx [n, cin] = fused gather-GEMM of dy over the REVERSE graph (weighted segment sums) with the
+ *   transposed weights WpT = ofx_pack_weights of W^T stacked over directions (K = 7*cout, N = cin, cin_pack =
+ *   cout, nt = 0).  nbr_rev / nbr_ext_rev / multi_seg come from the _w table builders above; aux: scratch of
+ *   (n_multi + 1) * ldy floats.
+ * _bwd_weight: dWp [Kp, cout] = col_data^T @ dy in the PACKED k order of ofx_pack_weights (k = dir*cin + c,
+ *   zero rows up to pad32(7*cin), then the 7*nt node-type rows), exact fp32 MFMA, deterministic slice-ordered
+ *   reduction.  ws holds the partial sums (and, for cin % 32 != 0, col-row chunks). */
+int ofx_graphconv_bwd_data(const float* dy, int64_t ldy, int cout, int64_t n_nodes, const int32_t* nbr_rev,
+                           const int32_t* rev_ptr, const int32_t* rev_row, const float* rev_w,
+                           const int32_t* nbr_ext_rev, const int32_t* multi_seg, int64_t n_multi, float* aux,
+                           const float* WpT, int64_t KpT, int cin, float* dx, int64_t ldx, void* ws, size_t ws_bytes,
+                           void* stream);
+int ofx_graphconv_bwd_weight(const float* x, int64_t ldx, int cin, int64_t n_nodes, const int32_t* nbr,
+                             const int32_t* seg_ptr, const int32_t* col, const int32_t* nbr_ext,
+                             const int32_t* multi_seg, int64_t n_multi, float* aux, const float* type_frac, int64_t ldt,
+                             int nt_pad, const float* dy, int64_t ldy, int cout, float* dWp, int64_t Kp, void* ws,
+                             size_t ws_bytes, void* stream);
 /* NeuralMPU SDF evaluation -- replaces NeuralMPU.__call__ / get_linear_pred / octree_linear_pts
  * (models/networks/dualoctree_networks/mpu.py:55-153), spmm / modulated_spmm (utils/spmm.py:12-61) and, with the
  * _grid entry, the sampling loop of calc_sdf (utils/util_dualoctree.py:99-118).

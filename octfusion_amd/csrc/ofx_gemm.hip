@@ -38,6 +38,7 @@ struct GemmArgs {
   const float* x; int64_t ldx; int cin; int ndir; int fast;   // fast: cin % 32 == 0 and aligned
   const int32_t* nbr;                                          // [M, ndir]: >=0 row, -1 none, -2 see CSR
   const int32_t* seg_ptr; const int32_t* col;                  // CSR by segment m*ndir+dir (for -2 entries)
+  const float* edge_w;                                         // NULL: segment MEAN; else per-edge weights, segment weighted SUM
   const float* tf; int64_t ldt; int64_t Kf;                    // Kf = pad32(ndir*cin)
   const int32_t* nbr_ext;                                      // fast path: [M, ndir] in [0, n_src + 1 + V)
   const float* aux; int64_t ldaux; int64_t n_src;              // aux row 0 = zeros, rows 1.. = multi-neighbour means
@@ -68,6 +69,14 @@ __device__ __forceinline__ float4 gather_seg4(const GemmArgs& g, int64_t row, in
   const int64_t s = row * g.ndir + dir;
   const int32_t a = g.seg_ptr[s], e = g.seg_ptr[s + 1];
   float4 acc = f4zero();
+  if (g.edge_w) {
+    for (int32_t p = a; p < e; ++p) {
+      const float w = g.edge_w[p];
+      const float4 v = *reinterpret_cast<const float4*>(g.x + (int64_t)g.col[p] * g.ldx + cc);
+      acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    }
+    return acc;
+  }
   for (int32_t p = a; p < e; ++p) f4add(acc, *reinterpret_cast<const float4*>(g.x + (int64_t)g.col[p] * g.ldx + cc));
   if (e - a > 1) {
     const float inv = 1.f / (float)(e - a);
@@ -86,6 +95,10 @@ __device__ __forceinline__ float gather_elem(const GemmArgs& g, int64_t row, int
   const int64_t s = row * g.ndir + dir;
   const int32_t a = g.seg_ptr[s], e = g.seg_ptr[s + 1];
   float acc = 0.f;
+  if (g.edge_w) {
+    for (int32_t p = a; p < e; ++p) acc += g.edge_w[p] * g.x[(int64_t)g.col[p] * g.ldx + c];
+    return acc;
+  }
   for (int32_t p = a; p < e; ++p) acc += g.x[(int64_t)g.col[p] * g.ldx + c];
   if (e - a > 1) acc /= (float)(e - a);
   return acc;
@@ -1083,7 +1096,8 @@ __global__ void __launch_bounds__(256) multi_mean_kernel(const float* __restrict
                                                          const int32_t* __restrict__ seg_ptr,
                                                          const int32_t* __restrict__ col,
                                                          const int32_t* __restrict__ multi_seg, int64_t V,
-                                                         float* __restrict__ aux, int64_t ldaux) {
+                                                         float* __restrict__ aux, int64_t ldaux,
+                                                         const float* __restrict__ w) {
   const int c4n = cin >> 2;
   const int64_t total = (V + 1) * c4n;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -1093,9 +1107,17 @@ __global__ void __launch_bounds__(256) multi_mean_kernel(const float* __restrict
     if (v > 0) {
       const int64_t s = multi_seg[v - 1];
       const int32_t a = seg_ptr[s], e = seg_ptr[s + 1];
-      for (int32_t p = a; p < e; ++p) f4add(acc, *reinterpret_cast<const float4*>(x + (int64_t)col[p] * ldx + c));
-      const float inv = 1.f / (float)(e - a);
-      acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+      if (w) {                                         // weighted sum (backward pass: reverse graph)
+        for (int32_t p = a; p < e; ++p) {
+          const float wp = w[p];
+          const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)col[p] * ldx + c);
+          acc.x += wp * xv.x; acc.y += wp * xv.y; acc.z += wp * xv.z; acc.w += wp * xv.w;
+        }
+      } else {
+        for (int32_t p = a; p < e; ++p) f4add(acc, *reinterpret_cast<const float4*>(x + (int64_t)col[p] * ldx + c));
+        const float inv = 1.f / (float)(e - a);
+        acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+      }
     }
     *reinterpret_cast<float4*>(aux + v * ldaux + c) = acc;
   }
@@ -1466,7 +1488,7 @@ extern "C" int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n
     if (n_multi < 0 || (n_multi > 0 && !multi_seg)) return OFX_EINVAL;
     // pre-pass: zero row + mean rows of the (few) segments with several neighbours
     multi_mean_kernel<<<ofx_grid((n_multi + 1) * (cin / 4), 256), 256, 0, st>>>(x, ldx, cin, seg_ptr, col, multi_seg,
-                                                                               n_multi, aux, ldx);
+                                                                               n_multi, aux, ldx, nullptr);
     g.nbr_ext = nbr_ext; g.aux = aux; g.ldaux = ldx; g.n_src = n_nodes;
     if (!g.tf) { g.tf = x; g.ldt = ldx; }       // never dereferenced past the gather tiles; keeps selects defined
   }
@@ -1476,6 +1498,227 @@ extern "C" int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n
     if (rc >= 0) return rc;
   }
   return launch_gemm<MODE_GATHER>(g, (float*)ws, ws_bytes, st);
+}
+
+// Backward of GraphConv with respect to its input (autograd of modules.py:205-213 + :213's matmul):
+//   dx[c, :] = sum_dir ( sum over reverse segment (c, dir) of rev_w * dy[rev_row, :] ) @ W_dir^T
+// = the same fused gather-GEMM run on the reverse graph with weighted segment SUMS and the transposed weights
+// (WpT: packed 'graphconv' layout of W^T_dir stacked over dir, K = 7 * cout, N = cin; the node-type rows of W
+// have no input gradient).
+extern "C" int ofx_graphconv_bwd_data(const float* dy, int64_t ldy, int cout, int64_t n_nodes, const int32_t* nbr_rev,
+                                      const int32_t* rev_ptr, const int32_t* rev_row, const float* rev_w,
+                                      const int32_t* nbr_ext_rev, const int32_t* multi_seg, int64_t n_multi, float* aux,
+                                      const float* WpT, int64_t KpT, int cin, float* dx, int64_t ldx, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  if (n_nodes == 0 && cin >= 1 && cout >= 1) return OFX_OK;
+  GemmArgs g = {};
+  int rc = gather_common(g, dy, ldy, cout, 7, n_nodes, nbr_rev, rev_ptr, rev_row, WpT, KpT, cin, nullptr, nullptr, 0,
+                         nullptr, nullptr, 0, dx, ldx);
+  if (rc) return rc;
+  if (!rev_ptr || !rev_row || !rev_w || KpT != g.Kf) return OFX_EINVAL;
+  g.edge_w = rev_w;
+  hipStream_t st = ofx_stream(stream);
+  if (g.fast && nbr_ext_rev && aux && (((uintptr_t)aux & 15) == 0)) {
+    if (n_multi < 0 || (n_multi > 0 && !multi_seg)) return OFX_EINVAL;
+    multi_mean_kernel<<<ofx_grid((n_multi + 1) * (cout / 4), 256), 256, 0, st>>>(dy, ldy, cout, rev_ptr, rev_row,
+                                                                                multi_seg, n_multi, aux, ldy, rev_w);
+    g.nbr_ext = nbr_ext_rev; g.aux = aux; g.ldaux = ldy; g.n_src = n_nodes;
+    g.tf = dy; g.ldt = ldy;
+  } else {
+    g.tf = dy; g.ldt = ldy;                       // col path: no type slab (Kp == Kf), never dereferenced
+    rc = launch_gather_via_col(g, (float*)ws, ws_bytes, st);
+    if (rc >= 0) return rc;
+  }
+  return launch_gemm<MODE_GATHER>(g, (float*)ws, ws_bytes, st);
+}
+
+// ---------------------------------------------------------------------------------
+// Backward of GraphConv with respect to its weights: dW[k, o] = sum_r col_data[r, k] * dy[r, o] -- a "TN"
+// contraction whose reduction index is the node row r of BOTH operands.  The 32x32x2 fp32 MFMA takes one
+// element per lane for each operand (A: row = lane & 31 at k = lane >> 5), so tiles that are contiguous along
+// k-of-W / o (= along the lanes) feed it straight from LDS without any transpose, in exact fp32.
+// col_data rows are gathered on the fly exactly like the forward pass (extended table + aux rows from the same
+// multi-neighbour pre-pass, node-type slab for the trailing columns); layers the branch-free gather cannot take
+// go through col_rows_kernel chunks with DENSE_P = true.
+// Grid: (k tiles of 128, o tiles of 128, row slices); partial sums [slice][Kp][cout] in the workspace, reduced in
+// slice order (deterministic).
+struct TnArgs {
+  const float* P; int64_t ldp;              // DENSE_P: col rows [rows, Kp]
+  const float* x; int64_t ldx; int cin;     // gathered P
+  const int32_t* nbr_ext; const float* aux; int64_t n_src;
+  const float* tf; int64_t ldt; int64_t Kf;
+  const float* Q; int64_t ldq;              // dy [rows, cout]
+  int64_t rows, row0, Kp, N;                // rows in this launch (starting at graph row row0), packed K, cout
+  int64_t rows_per_slice;
+  float* part;                              // [slices][Kp][N]
+};
+
+template <bool DENSE_P>
+__global__ void __launch_bounds__(256, 2) tn_gemm_kernel(const TnArgs a) {
+  constexpr int LD = 132;                   // LDS row pitch (floats): 128 + 4
+  __shared__ float Ps[32 * LD];
+  __shared__ float Qs[32 * LD];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * 128, n0 = (int64_t)blockIdx.y * 128;
+  const int64_t r_begin = (int64_t)blockIdx.z * a.rows_per_slice;
+  const int64_t r_end = r_begin + a.rows_per_slice < a.rows ? r_begin + a.rows_per_slice : a.rows;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int kr = threadIdx.x >> 3;          // tile row (node) this thread loads, 0..31
+  const int f0 = threadIdx.x & 7;           // float4 column f0 + 8 p, p < 4
+  float4 vp[4], vq[4];
+  auto load_tile = [&](int64_t r) {
+    const int64_t row = r + kr;
+    const bool rok = row < r_end;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t m = m0 + 4 * (f0 + 8 * p), n = n0 + 4 * (f0 + 8 * p);
+      float4 v = f4zero();
+      if (rok && m < a.Kp) {
+        if (DENSE_P) {
+          v = *reinterpret_cast<const float4*>(a.P + row * a.ldp + m);
+        } else if (m < a.Kf) {
+          const int64_t kk = m;
+          if (kk < 7 * (int64_t)a.cin) {
+            const int dir = (int)(kk / a.cin), c = (int)(kk - (int64_t)dir * a.cin);
+            const int64_t id = a.nbr_ext[(a.row0 + row) * 7 + dir];
+            const float* src = id < a.n_src ? a.x + id * a.ldx : a.aux + (id - a.n_src) * a.ldx;
+            v = *reinterpret_cast<const float4*>(src + c);
+          }
+        } else {
+          v = *reinterpret_cast<const float4*>(a.tf + (a.row0 + row) * a.ldt + (m - a.Kf));
+        }
+      }
+      vp[p] = v;
+      float4 q = f4zero();
+      if (rok && n < a.N) q = *reinterpret_cast<const float4*>(a.Q + row * a.ldq + n);   // N % 4 == 0
+      vq[p] = q;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<float4*>(Ps + kr * LD + 4 * (f0 + 8 * p)) = vp[p];
+      *reinterpret_cast<float4*>(Qs + kr * LD + 4 * (f0 + 8 * p)) = vq[p];
+    }
+  };
+  if (r_begin < r_end) load_tile(r_begin);
+  for (int64_t r = r_begin; r < r_end; r += 32) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (r + 32 < r_end) load_tile(r + 32);
+    const float* pa = Ps + h * LD + wm * 64 + l31;
+    const float* pb = Qs + h * LD + wn * 64 + l31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float a0 = pa[2 * q * LD], a1 = pa[2 * q * LD + 32];
+      const float b0 = pb[2 * q * LD], b1 = pb[2 * q * LD + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+  float* out = a.part + (int64_t)blockIdx.z * a.Kp * a.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 32 + l31;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < a.Kp) out[m * a.N + n] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256) tn_reduce_kernel(const float* __restrict__ part, int slices, int64_t total,
+                                                         float* __restrict__ dW, int accumulate) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    float v = accumulate ? dW[t] : 0.f;
+    for (int s2 = 0; s2 < slices; ++s2) v += part[(int64_t)s2 * total + t];
+    dW[t] = v;
+  }
+}
+
+// dWp: [Kp, cout] in the PACKED k order of ofx_pack_weights (k = dir*cin + c, zero rows up to Kf, then the
+// node-type rows).  aux must hold the forward pre-pass rows (ofx_graphconv_fwd leaves them there) when
+// nbr_ext is given; it is recomputed here so the call is self-contained.
+extern "C" int ofx_graphconv_bwd_weight(const float* x, int64_t ldx, int cin, int64_t n_nodes, const int32_t* nbr,
+                                        const int32_t* seg_ptr, const int32_t* col, const int32_t* nbr_ext,
+                                        const int32_t* multi_seg, int64_t n_multi, float* aux, const float* type_frac,
+                                        int64_t ldt, int nt_pad, const float* dy, int64_t ldy, int cout, float* dWp,
+                                        int64_t Kp, void* ws, size_t ws_bytes, void* stream) {
+  if (n_nodes < 0 || cin < 1 || cout < 1 || (cout & 3) || !dy || !dWp || !ws || ldy < cout || (ldy & 3) ||
+      ((uintptr_t)dy & 15) || ((uintptr_t)ws & 15) || (n_nodes > 0 && (!x || !nbr || !seg_ptr || !col)))
+    return OFX_EINVAL;
+  const int64_t Kf = pad32(7 * (int64_t)cin);
+  if (nt_pad < 0 || (nt_pad & 31) || Kp != Kf + nt_pad) return OFX_EINVAL;
+  if (nt_pad > 0 && (!type_frac || ldt < nt_pad || (ldt & 3) || ((uintptr_t)type_frac & 15))) return OFX_EINVAL;
+  hipStream_t st = ofx_stream(stream);
+  const int64_t total = Kp * cout;
+  if (n_nodes == 0) {
+    if (hipMemsetAsync(dWp, 0, (size_t)total * sizeof(float), st) != hipSuccess) return OFX_ELAUNCH;
+    return OFX_OK;
+  }
+  const bool fast = (cin % 32 == 0) && ((ldx & 3) == 0) && (((uintptr_t)x & 15) == 0) && nbr_ext && aux &&
+                    (((uintptr_t)aux & 15) == 0);
+  const int tiles = (int)(ofx_cdiv(Kp, 128) * ofx_cdiv(cout, 128));
+  TnArgs a = {};
+  a.Q = dy; a.ldq = ldy; a.Kp = Kp; a.N = cout; a.Kf = Kf;
+  if (fast) {
+    if (n_multi < 0 || (n_multi > 0 && !multi_seg)) return OFX_EINVAL;
+    multi_mean_kernel<<<ofx_grid((n_multi + 1) * (cin / 4), 256), 256, 0, st>>>(x, ldx, cin, seg_ptr, col, multi_seg,
+                                                                               n_multi, aux, ldx, nullptr);
+    int slices = (int)ofx_cdiv(1024, tiles);
+    if (slices > 256) slices = 256;
+    while (slices > 1 && (size_t)slices * total * sizeof(float) > ws_bytes) --slices;
+    if ((size_t)slices * total * sizeof(float) > ws_bytes) return OFX_EINVAL;
+    a.x = x; a.ldx = ldx; a.cin = cin; a.nbr_ext = nbr_ext; a.aux = aux; a.n_src = n_nodes;
+    a.tf = type_frac ? type_frac : x; a.ldt = type_frac ? ldt : ldx;
+    a.rows = n_nodes; a.row0 = 0;
+    a.rows_per_slice = ofx_cdiv(ofx_cdiv(n_nodes, slices), 32) * 32;
+    slices = (int)ofx_cdiv(n_nodes, a.rows_per_slice);
+    a.part = (float*)ws;
+    tn_gemm_kernel<false><<<dim3((unsigned)ofx_cdiv(Kp, 128), (unsigned)ofx_cdiv(cout, 128), (unsigned)slices), 256, 0, st>>>(a);
+    tn_reduce_kernel<<<ofx_grid(total, 256), 256, 0, st>>>(a.part, slices, total, dWp, 0);
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+  }
+  // generic layers: col rows materialised chunk by chunk in the first part of the workspace
+  GemmArgs g = {};
+  g.x = x; g.ldx = ldx; g.cin = cin; g.ndir = 7; g.nbr = nbr; g.seg_ptr = seg_ptr; g.col = col;
+  g.tf = type_frac; g.ldt = ldt; g.Kf = Kf; g.Kp = Kp; g.M = n_nodes;
+  int slices = (int)ofx_cdiv(512, tiles);
+  if (slices > 64) slices = 64;
+  const size_t part_bytes = ((size_t)slices * total * sizeof(float) + 255) & ~size_t(255);
+  if (part_bytes >= ws_bytes) return OFX_EINVAL;
+  int64_t chunk = (int64_t)((ws_bytes - part_bytes) / ((size_t)Kp * sizeof(float))) / 32 * 32;
+  if (chunk < 32) return OFX_EINVAL;
+  float* colbuf = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + part_bytes);
+  a.P = colbuf; a.ldp = Kp; a.part = (float*)ws;
+  int first = 1;
+  for (int64_t r0 = 0; r0 < n_nodes; r0 += chunk) {
+    const int64_t rows = n_nodes - r0 < chunk ? n_nodes - r0 : chunk;
+    col_rows_kernel<<<ofx_grid(rows * (Kp >> 2), 256), 256, 0, st>>>(g, r0, rows, colbuf);
+    a.Q = dy + r0 * ldy; a.rows = rows; a.row0 = r0;
+    a.rows_per_slice = ofx_cdiv(ofx_cdiv(rows, slices), 32) * 32;
+    const int sl = (int)ofx_cdiv(rows, a.rows_per_slice);
+    tn_gemm_kernel<true><<<dim3((unsigned)ofx_cdiv(Kp, 128), (unsigned)ofx_cdiv(cout, 128), (unsigned)sl), 256, 0, st>>>(a);
+    tn_reduce_kernel<<<ofx_grid(total, 256), 256, 0, st>>>(a.part, sl, total, dWp, first ? 0 : 1);
+    first = 0;
+  }
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
 }
 
 extern "C" int ofx_gridconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_in, int64_t n_out,

@@ -534,3 +534,115 @@ extern "C" int ofx_mpu_eval_grid(const ofx_tree_t* tree, int depth_start, int de
   a.size = size; a.batch = batch_index; a.step = step; a.bbmin = bbmin; a.head = head;
   return mpu_launch(tree, a, ofx_stream(stream));
 }
+
+// ---------------------------------------------------------------------------------
+// Reverse graph for the backward pass of GraphConv (reference: autograd of modules.py:194-220, i.e. of
+// index_select + scatter_mean): forward segment (r, dir) averages x[col] over its cnt edges, so
+//   dx[c] = sum over forward edges e with col_e = c of dcol[row_e, dir_e] / cnt(row_e, dir_e).
+// The reverse CSR is keyed by (c, dir): rev_row[e] = row_e, rev_w[e] = 1 / cnt(row_e, dir_e), each reverse
+// segment sorted by row so the summation order is fixed.
+__global__ void rev_count_kernel(const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ col, int64_t nseg,
+                                 int32_t* __restrict__ rcnt) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * blockDim.x) {
+    const int dir = (int)(s % 7);
+    for (int32_t p = seg_ptr[s]; p < seg_ptr[s + 1]; ++p) atomicAdd(&rcnt[(int64_t)col[p] * 7 + dir], 1);
+  }
+}
+__global__ void rev_fill_kernel(const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ col, int64_t nseg,
+                                const int32_t* __restrict__ rev_ptr, int32_t* __restrict__ cursor,
+                                int32_t* __restrict__ rev_row, float* __restrict__ rev_w) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * blockDim.x) {
+    const int dir = (int)(s % 7);
+    const int32_t a = seg_ptr[s], e = seg_ptr[s + 1];
+    const float w = 1.0f / (float)(e - a > 0 ? e - a : 1);
+    for (int32_t p = a; p < e; ++p) {
+      const int64_t key = (int64_t)col[p] * 7 + dir;
+      const int32_t pos = rev_ptr[key] + atomicAdd(&cursor[key], 1);
+      rev_row[pos] = (int32_t)(s / 7);
+      rev_w[pos] = w;
+    }
+  }
+}
+__global__ void rev_sort_kernel(const int32_t* __restrict__ rev_ptr, int64_t nseg, int32_t* __restrict__ rev_row,
+                                float* __restrict__ rev_w) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t a = rev_ptr[s], e = rev_ptr[s + 1];
+    for (int32_t i = a + 1; i < e; ++i) {                    // insertion sort: segments hold <= a handful of edges
+      const int32_t r = rev_row[i];
+      const float w = rev_w[i];
+      int32_t j = i - 1;
+      while (j >= a && rev_row[j] > r) { rev_row[j + 1] = rev_row[j]; rev_w[j + 1] = rev_w[j]; --j; }
+      rev_row[j + 1] = r; rev_w[j + 1] = w;
+    }
+  }
+}
+extern "C" int ofx_graph_reverse_count(const int32_t* seg_ptr, const int32_t* col, int64_t n_nodes, int32_t* rev_cnt,
+                                       void* stream) {
+  if (!seg_ptr || !rev_cnt || n_nodes < 0) return OFX_EINVAL;
+  if (n_nodes == 0) return OFX_OK;
+  if (hipMemsetAsync(rev_cnt, 0, (size_t)n_nodes * 7 * sizeof(int32_t), ofx_stream(stream)) != hipSuccess) return OFX_ELAUNCH;
+  rev_count_kernel<<<ofx_grid(n_nodes * 7, 256), 256, 0, ofx_stream(stream)>>>(seg_ptr, col, n_nodes * 7, rev_cnt);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+extern "C" int ofx_graph_reverse_fill(const int32_t* seg_ptr, const int32_t* col, int64_t n_nodes, const int32_t* rev_ptr,
+                                      int32_t* cursor, int32_t* rev_row, float* rev_w, void* stream) {
+  if (!seg_ptr || !rev_ptr || !cursor || !rev_row || !rev_w || n_nodes < 0) return OFX_EINVAL;
+  if (n_nodes == 0) return OFX_OK;
+  hipStream_t st = ofx_stream(stream);
+  if (hipMemsetAsync(cursor, 0, (size_t)n_nodes * 7 * sizeof(int32_t), st) != hipSuccess) return OFX_ELAUNCH;
+  rev_fill_kernel<<<ofx_grid(n_nodes * 7, 256), 256, 0, st>>>(seg_ptr, col, n_nodes * 7, rev_ptr, cursor, rev_row, rev_w);
+  rev_sort_kernel<<<ofx_grid(n_nodes * 7, 256), 256, 0, st>>>(rev_ptr, n_nodes * 7, rev_row, rev_w);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+// weighted variants of graph_primary / multi_flag / primary_ext: a segment is "simple" (one source row, used as
+// is) only when it has exactly one edge of weight 1
+__global__ void graph_primary_w_kernel(const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ col,
+                                       const float* __restrict__ w, int64_t nseg, int32_t* __restrict__ nbr) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t a = seg_ptr[s], e = seg_ptr[s + 1];
+    nbr[s] = e == a ? -1 : ((e - a == 1 && w[a] == 1.0f) ? col[a] : -2);
+  }
+}
+__global__ void graph_multi_flag_w_kernel(const int32_t* __restrict__ seg_ptr, const float* __restrict__ w, int64_t nseg,
+                                          int32_t* __restrict__ flag) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t a = seg_ptr[s], e = seg_ptr[s + 1];
+    flag[s] = (e - a > 1) || (e - a == 1 && w[a] != 1.0f);
+  }
+}
+__global__ void graph_primary_ext_w_kernel(const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ col,
+                                           const float* __restrict__ w, int64_t nseg, int64_t N,
+                                           const int32_t* __restrict__ rank, int32_t* __restrict__ nbr_ext,
+                                           int32_t* __restrict__ multi_seg) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t a = seg_ptr[s], e = seg_ptr[s + 1];
+    if (e == a) nbr_ext[s] = (int32_t)N;
+    else if (e - a == 1 && w[a] == 1.0f) nbr_ext[s] = col[a];
+    else { nbr_ext[s] = (int32_t)(N + 1 + rank[s]); multi_seg[rank[s]] = (int32_t)s; }
+  }
+}
+extern "C" int ofx_graph_primary_w(const int32_t* seg_ptr, const int32_t* col, const float* w, int64_t n_nodes,
+                                   int32_t* nbr, void* stream) {
+  if (!seg_ptr || !nbr || n_nodes < 0) return OFX_EINVAL;
+  graph_primary_w_kernel<<<ofx_grid(n_nodes * 7, 256), 256, 0, ofx_stream(stream)>>>(seg_ptr, col, w, n_nodes * 7, nbr);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+extern "C" int ofx_graph_multi_flag_w(const int32_t* seg_ptr, const float* w, int64_t n_nodes, int32_t* flag,
+                                      void* stream) {
+  if (!seg_ptr || !flag || n_nodes < 0) return OFX_EINVAL;
+  graph_multi_flag_w_kernel<<<ofx_grid(n_nodes * 7, 256), 256, 0, ofx_stream(stream)>>>(seg_ptr, w, n_nodes * 7, flag);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+extern "C" int ofx_graph_primary_ext_w(const int32_t* seg_ptr, const int32_t* col, const float* w, int64_t n_nodes,
+                                       const int32_t* rank, int32_t* nbr_ext, int32_t* multi_seg, void* stream) {
+  if (!seg_ptr || !rank || !nbr_ext || n_nodes < 0) return OFX_EINVAL;
+  graph_primary_ext_w_kernel<<<ofx_grid(n_nodes * 7, 256), 256, 0, ofx_stream(stream)>>>(
+      seg_ptr, col, w, n_nodes * 7, n_nodes, rank, nbr_ext, multi_seg);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}

@@ -79,6 +79,7 @@ class DualOctree:
         self._csr = {}
         self._nbr = {}
         self._ext = {}
+        self._rev = {}
         self._bid32 = {}
         self._count = {}
         self._tf = {}
@@ -168,6 +169,38 @@ class DualOctree:
     def ext(self, d):
         """(nbr_ext int32 [N*7], multi_seg int32 [V], V): the branch-free gather table (ofx.h)."""
         return self._ext[d]
+
+    def rev(self, d):
+        """Reverse graph of depth d for GraphConv's backward pass (ofx.h): dict with rev_ptr [N*7+1], rev_row [E],
+        rev_w [E] (1 / size of the forward segment the edge came from), nbr (primary table), nbr_ext, multi_seg, V.
+        Built on first use."""
+        if d in self._rev:
+            return self._rev[d]
+        seg_ptr, col, N, E = self._csr[d]
+        dev = self.device
+        cnt = torch.empty(N * 7, dtype=torch.int32, device=dev)
+        call('ofx_graph_reverse_count', ptr(seg_ptr), ptr(col), N, ptr(cnt), stream())
+        rev_ptr = torch.empty(N * 7 + 1, dtype=torch.int32, device=dev)
+        ws = torch.empty(_lib.lib().ofx_scan_ws_bytes(N * 7), dtype=torch.uint8, device=dev)
+        call('ofx_scan_i32', ptr(cnt), ptr(rev_ptr), N * 7, ptr(ws), stream())
+        rev_row = torch.empty(E, dtype=torch.int32, device=dev)
+        rev_w = torch.empty(E, dtype=torch.float32, device=dev)
+        call('ofx_graph_reverse_fill', ptr(seg_ptr), ptr(col), N, ptr(rev_ptr), ptr(cnt), ptr(rev_row), ptr(rev_w),
+             stream())
+        nbr = torch.empty(N * 7, dtype=torch.int32, device=dev)
+        call('ofx_graph_primary_w', ptr(rev_ptr), ptr(rev_row), ptr(rev_w), N, ptr(nbr), stream())
+        flag = cnt
+        call('ofx_graph_multi_flag_w', ptr(rev_ptr), ptr(rev_w), N, ptr(flag), stream())
+        rank = torch.empty(N * 7 + 1, dtype=torch.int32, device=dev)
+        call('ofx_scan_i32', ptr(flag), ptr(rank), N * 7, ptr(ws), stream())
+        V = int(rank[-1].item())
+        nbr_ext = torch.empty(N * 7, dtype=torch.int32, device=dev)
+        multi_seg = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
+        call('ofx_graph_primary_ext_w', ptr(rev_ptr), ptr(rev_row), ptr(rev_w), N, ptr(rank), ptr(nbr_ext),
+             ptr(multi_seg), stream())
+        self._rev[d] = dict(rev_ptr=rev_ptr, rev_row=rev_row, rev_w=rev_w, nbr=nbr, nbr_ext=nbr_ext,
+                            multi_seg=multi_seg, V=V, N=N, E=E)
+        return self._rev[d]
 
     def batch_id32(self, d):
         return self._bid32[d]

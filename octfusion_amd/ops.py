@@ -192,6 +192,53 @@ def graphconv(x, nbr, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None
     return out
 
 
+def graphconv_backward(x, dy, doctree, d, weights, n_node_type, need_dx=True, need_dw=True):
+    """Gradients of y = GraphConv(x) (modules.py:194-220) w.r.t. x and the weights, given dy = dL/dy.
+    Returns (dx [N, Cin] or None, dW [7*(Cin+nt'), Cout] or None) -- training path, SURVEY 8f-4."""
+    x, ldx = _row_major(x)
+    dy, ldy = _row_major(dy)
+    _chk(x), _chk(dy), _chk(weights)
+    N, cin = x.shape
+    cout = dy.shape[1]
+    nt = n_node_type if n_node_type > 1 else 0
+    assert weights.shape == (7 * (cin + nt), cout)
+    seg_ptr, col, Ng, E = doctree.csr(d)
+    assert N == Ng and dy.shape[0] == N
+    ws = workspace(x.device)
+    dx = dW = None
+    if need_dx:
+        rv = doctree.rev(d)
+        wt = weights.detach().view(7, cin + nt, cout)[:, :cin, :].permute(0, 2, 1).reshape(7 * cout, cin).contiguous()
+        pwt = PackedWeight().get(wt, 'graphconv', cout, 0)
+        dx = torch.empty(N, cin, dtype=torch.float32, device=x.device)
+        fast = cout % 32 == 0 and ldy % 4 == 0
+        aux = torch.empty((rv['V'] + 1) * ldy, dtype=torch.float32, device=x.device) if fast else None
+        call('ofx_graphconv_bwd_data', ptr(dy), ldy, cout, N, ptr(rv['nbr']), ptr(rv['rev_ptr']), ptr(rv['rev_row']),
+             ptr(rv['rev_w']), ptr(rv['nbr_ext']) if fast else None, ptr(rv['multi_seg']) if fast else None,
+             rv['V'] if fast else 0, ptr(aux), ptr(pwt.t), pwt.Kp, cin, ptr(dx), cin, ptr(ws), ws.numel(), stream())
+    if need_dw:
+        L = _lib.lib()
+        Kp = L.ofx_graphconv_packed_k(cin, nt)
+        Kf = Kp - (((7 * nt + 31) // 32) * 32 if nt else 0)
+        tf = doctree.type_frac(d, nt) if nt else None
+        fast = cin % 32 == 0 and ldx % 4 == 0
+        nbr_ext, multi_seg, V = doctree.ext(d)
+        aux = torch.empty((V + 1) * ldx, dtype=torch.float32, device=x.device) if fast else None
+        dwp = torch.empty(Kp, cout, dtype=torch.float32, device=x.device)
+        call('ofx_graphconv_bwd_weight', ptr(x), ldx, cin, N, ptr(doctree.nbr(d)), ptr(seg_ptr), ptr(col),
+             ptr(nbr_ext) if fast else None, ptr(multi_seg) if fast else None, V if fast else 0, ptr(aux),
+             ptr(tf), tf.stride(0) if tf is not None else 0, tf.shape[1] if tf is not None else 0,
+             ptr(dy), ldy, cout, ptr(dwp), Kp, ptr(ws), ws.numel(), stream())
+        # packed k order -> the reference's row order dir*(cin+nt) + [channels | types]
+        dev = x.device
+        dirs = torch.arange(7, device=dev).view(7, 1)
+        idx = [dirs * cin + torch.arange(cin, device=dev).view(1, cin)]
+        if nt:
+            idx.append(Kf + dirs * nt + torch.arange(nt, device=dev).view(1, nt))
+        dW = dwp.index_select(0, torch.cat(idx, 1).reshape(-1))
+    return dx, dW
+
+
 class PackedConv3d:
     """nn.Conv3d weight [cout, cin, 3, 3, 3] packed for the 27-tap gather-GEMM."""
 

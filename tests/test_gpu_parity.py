@@ -298,6 +298,46 @@ def test_fused_statistics_and_edge_shapes():
             close(y, (A.double() @ W.double() + b.double()).float(), 1e-4)
 
 
+def test_graphconv_backward_vs_autograd():
+    """Training path: dx (fused gather-GEMM over the reverse graph) and dW (TN fp32-MFMA kernel)
+    against torch.autograd of the fp64 oracle GraphConv, on fast and generic layer shapes; the reverse graph
+    itself against a host construction."""
+    from octfusion_amd import ops
+    from oracle import dual_octree as OD, modules as OM, sampler as OS
+    split = C.random_split_small(3, 3, 51, p=0.45)
+    oc, doc = small(split)
+    o_doc = OD.OracleDualOctree(OS.split2octree_small(split, 5, 3))
+    o_doc.post_processing_for_docnn()
+    # reverse graph == transpose of the forward edge list with weights 1 / |forward segment|
+    for d in (4, 5):
+        g = o_doc.graph[d]
+        row, col = g['edge_idx']
+        key = row * 7 + g['edge_dir']
+        cnt = torch.bincount(key, minlength=int(key.max()) + 1)[key].float()
+        rkey = col * 7 + g['edge_dir']
+        order = torch.argsort(rkey * (int(row.max()) + 1) + row)
+        rv = doc.rev(d)
+        n7 = doc.csr(d)[2] * 7
+        assert torch.equal(rv['rev_ptr'].cpu().long(),
+                           torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(torch.bincount(rkey, minlength=n7), 0)]))
+        assert torch.equal(rv['rev_row'].cpu().long(), row[order])
+        assert torch.equal(rv['rev_w'].cpu(), (1.0 / cnt)[order])
+    for d, cin, cout, nt in [(5, 64, 128, 4), (4, 32, 96, 3), (5, 96, 32, 0), (5, 3, 64, 4), (4, 64, 4, 3)]:
+        ntt = nt if nt > 1 else 0
+        N = doc.csr(d)[2]
+        x = C.rand_input('bx%d_%d' % (d, cin), N, cin)
+        dy = C.rand_input('bdy%d_%d' % (d, cout), N, cout)
+        W = C.rand_input('bw%d_%d' % (cin, cout), 7 * (cin + ntt), cout) * 0.1
+        with torch.enable_grad():
+            x64 = x.double().requires_grad_(True)
+            W64 = W.double().requires_grad_(True)
+            y = OM.graph_conv(x64, o_doc, d, W64, None, nt)
+            (y * dy.double()).sum().backward()
+        dx, dW = ops.graphconv_backward(x.to(dev()), dy.to(dev()), doc, d, W.to(dev()), nt)
+        close(dx, x64.grad.float(), 1e-4)
+        close(dW, W64.grad.float(), 1e-5)
+
+
 def to_rows(vox, depth):
     from octfusion_amd import ops
     return ops.voxel2octree_cf(vox.to(dev()).contiguous(), depth)

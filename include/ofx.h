@@ -167,6 +167,13 @@ int ofx_graphconv_bwd_weight(const float* x, int64_t ldx, int cin, int64_t n_nod
                              const int32_t* multi_seg, int64_t n_multi, float* aux, const float* type_frac, int64_t ldt,
                              int nt_pad, const float* dy, int64_t ldy, int cout, float* dWp, int64_t Kp, void* ws,
                              size_t ws_bytes, void* stream);
+/* Backward of DualOctreeGroupNorm (+ fused activation) -- training path, autograd of modules.py:291-326.
+ * mean / rstd [B*C] are the forward statistics (ofx_gn_finalize).  sums [B*C*2] fp64 and coef [B*C*3] fp32 are
+ * scratch.  Outputs dx [n, C], dgamma [C], dbeta [C]. */
+int ofx_gn_backward(const float* x, int64_t ldx, const float* dy, int64_t ldy, int64_t n, int C,
+                    const int32_t* batch_id, int batch_size, const float* count, int groups, float count_eps,
+                    const float* mean, const float* rstd, const float* w, const float* bias, int act, double* sums,
+                    float* coef, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* stream);
 /* NeuralMPU SDF evaluation -- replaces NeuralMPU.__call__ / get_linear_pred / octree_linear_pts
  * (models/networks/dualoctree_networks/mpu.py:55-153), spmm / modulated_spmm (utils/spmm.py:12-61) and, with the
  * _grid entry, the sampling loop of calc_sdf (utils/util_dualoctree.py:99-118).

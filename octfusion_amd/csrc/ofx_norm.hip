@@ -183,3 +183,163 @@ extern "C" int ofx_act(const float* x, float* y, int64_t n, int act, void* strea
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
+
+// ---------------------------------------------------------------------------------
+// Backward of DualOctreeGroupNorm (+ fused SiLU / GELU) -- training path, autograd of modules.py:291-326.
+// With n = count*cpg, inv = 1/(n + count_eps), mu = inv*sum(x), d = x - mu, v = inv*sum(d^2), r = (v+eps)^-1/2,
+// y = d*r*gamma + beta, g = dL/dy * act'(y):
+//   per (batch element, channel):  A = sum_i g,  Bc = sum_i g*x          (one pass over x and dy)
+//   per (batch element, group):    S1 = sum_c gamma*A,  S2 = sum_c gamma*(Bc - mu*A),
+//                                  dv = -r^3*S2/2,  c2 = 2*inv*dv,  c3 = -inv*(r*S1 + c2*mu*count_eps)
+//   dx = gamma*r*g + c2*(x - mu) + c3,   dgamma = sum_b r*(Bc - mu*A),   dbeta = sum_b A.
+// (sum_i d = mu*count_eps because the reference divides by n + eps, not n.)
+__device__ __forceinline__ float ofx_act_grad(float y, int act) {
+  if (act == OFX_ACT_SILU) {
+    const float s = 1.f / (1.f + __expf(-y));
+    return s * (1.f + y * (1.f - s));
+  }
+  if (act == OFX_ACT_GELU)
+    return 0.5f * (1.f + erff(y * 0.70710678118654752440f)) + y * 0.3989422804014327f * __expf(-0.5f * y * y);
+  return 1.f;
+}
+
+// thread = (row lane, float4 of channels); per-thread run accumulation, one fp64 atomic pair per channel per run
+__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           const float* __restrict__ dy, int64_t ldy, int64_t n, int C,
+                                                           const int32_t* __restrict__ bid,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           int act, double* __restrict__ sums) {
+  const int CT = C >> 2, RP = 256 / CT;
+  const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
+  if (rl >= RP) return;
+  const int64_t r_begin = (int64_t)blockIdx.x * 64;
+  const int64_t r_end = r_begin + 64 < n ? r_begin + 64 : n;
+  const float4 ww = *reinterpret_cast<const float4*>(w + cl * 4);
+  const float4 bb = *reinterpret_cast<const float4*>(bias + cl * 4);
+  int cb = -1;
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  auto flush = [&]() {
+    if (cb < 0) return;
+    double* o = sums + ((int64_t)cb * C + cl * 4) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { unsafeAtomicAdd(o + 2 * k, (double)s[k]); unsafeAtomicAdd(o + 2 * k + 1, (double)q[k]); }
+  };
+  for (int64_t r = r_begin + rl; r < r_end; r += RP) {
+    const int b = bid[r];
+    if (b != cb) { flush(); cb = b; s[0] = s[1] = s[2] = s[3] = 0.f; q[0] = q[1] = q[2] = q[3] = 0.f; }
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + cl * 4);
+    float4 g = *reinterpret_cast<const float4*>(dy + r * ldy + cl * 4);
+    if (act != OFX_ACT_NONE) {
+      const float4 m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + cl * 4);
+      const float4 rs = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + cl * 4);
+      g.x *= ofx_act_grad((xv.x - m.x) * rs.x * ww.x + bb.x, act);
+      g.y *= ofx_act_grad((xv.y - m.y) * rs.y * ww.y + bb.y, act);
+      g.z *= ofx_act_grad((xv.z - m.z) * rs.z * ww.z + bb.z, act);
+      g.w *= ofx_act_grad((xv.w - m.w) * rs.w * ww.w + bb.w, act);
+    }
+    s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+    q[0] += g.x * xv.x; q[1] += g.y * xv.y; q[2] += g.z * xv.z; q[3] += g.w * xv.w;
+  }
+  flush();
+}
+
+__global__ void gn_bwd_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ count, int B, int C,
+                                       int G, float count_eps, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, const float* __restrict__ w,
+                                       float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int cpg = C / G;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < B * G) {
+    const int b = t / G, g = t - b * G;
+    const double mu = mean[(int64_t)b * C + g * cpg], r = rstd[(int64_t)b * C + g * cpg];
+    double S1 = 0, S2 = 0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      const double A = sums[((int64_t)b * C + c) * 2], Bc = sums[((int64_t)b * C + c) * 2 + 1];
+      S1 += (double)w[c] * A;
+      S2 += (double)w[c] * (Bc - mu * A);
+    }
+    const double nn = (double)(count[b] * (float)cpg);
+    const double inv = 1.0 / (double)((float)nn + count_eps);
+    const double dv = -0.5 * r * r * r * S2;
+    const double c2 = 2.0 * inv * dv;
+    const double c3 = -inv * (r * S1 + c2 * mu * (double)count_eps);
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      float* o = coef + ((int64_t)b * C + c) * 3;
+      o[0] = (float)((double)w[c] * r);
+      o[1] = (float)c2;
+      o[2] = (float)(c3 - c2 * mu);
+    }
+  }
+  // dgamma / dbeta: one thread per channel over the (few) batch elements, after a grid-wide dependency-free split:
+  // they only need sums / mean / rstd, not coef
+  if (t < C) {
+    double dg = 0, db = 0;
+    for (int b = 0; b < B; ++b) {
+      const double A = sums[((int64_t)b * C + t) * 2], Bc = sums[((int64_t)b * C + t) * 2 + 1];
+      dg += (double)rstd[(int64_t)b * C + t] * (Bc - (double)mean[(int64_t)b * C + t] * A);
+      db += A;
+    }
+    dgamma[t] = (float)dg;
+    dbeta[t] = (float)db;
+  }
+}
+
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           const float* __restrict__ dy, int64_t ldy, int64_t n, int C,
+                                                           const int32_t* __restrict__ bid, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int act,
+                                                           const float* __restrict__ coef, float* __restrict__ dx,
+                                                           int64_t lddx) {
+  const int CT = C >> 2;
+  const int64_t total = n * CT;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / CT;
+    const int c = (int)(t - r * CT) * 4;
+    const int b = bid[r];
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    float4 g = *reinterpret_cast<const float4*>(dy + r * ldy + c);
+    if (act != OFX_ACT_NONE) {
+      const float4 m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c);
+      const float4 rs = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c);
+      const float4 ww = *reinterpret_cast<const float4*>(w + c);
+      const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+      g.x *= ofx_act_grad((xv.x - m.x) * rs.x * ww.x + bb.x, act);
+      g.y *= ofx_act_grad((xv.y - m.y) * rs.y * ww.y + bb.y, act);
+      g.z *= ofx_act_grad((xv.z - m.z) * rs.z * ww.z + bb.z, act);
+      g.w *= ofx_act_grad((xv.w - m.w) * rs.w * ww.w + bb.w, act);
+    }
+    const float* k = coef + ((int64_t)b * C + c) * 3;
+    float4 o;
+    o.x = k[0] * g.x + k[1] * xv.x + k[2];
+    o.y = k[3] * g.y + k[4] * xv.y + k[5];
+    o.z = k[6] * g.z + k[7] * xv.z + k[8];
+    o.w = k[9] * g.w + k[10] * xv.w + k[11];
+    *reinterpret_cast<float4*>(dx + r * lddx + c) = o;
+  }
+}
+
+extern "C" int ofx_gn_backward(const float* x, int64_t ldx, const float* dy, int64_t ldy, int64_t n, int C,
+                               const int32_t* batch_id, int batch_size, const float* count, int groups,
+                               float count_eps, const float* mean, const float* rstd, const float* w, const float* bias,
+                               int act, double* sums, float* coef, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                               void* stream) {
+  if (!x || !dy || !batch_id || !count || !mean || !rstd || !w || !bias || !sums || !coef || !dx || !dgamma || !dbeta ||
+      n < 0 || C < 4 || (C & 3) || C > 1024 || groups < 1 || C % groups || batch_size < 1 || ldx < C || ldy < C ||
+      lddx < C || ((ldx | ldy | lddx) & 3) || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) ||
+      act < 0 || act > OFX_ACT_GELU)
+    return OFX_EINVAL;
+  hipStream_t st = ofx_stream(stream);
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)batch_size * C, st) != hipSuccess) return OFX_ELAUNCH;
+  if (n > 0)
+    gn_bwd_stats_kernel<<<(int)ofx_cdiv(n, 64), 256, 0, st>>>(x, ldx, dy, ldy, n, C, batch_id, mean, rstd, w, bias, act, sums);
+  const int work = batch_size * groups > C ? batch_size * groups : C;
+  gn_bwd_finalize_kernel<<<(work + 63) / 64, 64, 0, st>>>(sums, count, batch_size, C, groups, count_eps, mean, rstd, w,
+                                                          coef, dgamma, dbeta);
+  if (n > 0)
+    gn_bwd_apply_kernel<<<ofx_grid(n * (C >> 2), 256), 256, 0, st>>>(x, ldx, dy, ldy, n, C, batch_id, mean, rstd, w,
+                                                                     bias, act, coef, dx, lddx);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}

@@ -357,6 +357,33 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
     return out
 
 
+def group_norm_backward(x, dy, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, act=None, count_eps=None):
+    """(dx, dgamma, dbeta) of y = act(DualOctreeGroupNorm(x)) given dy -- training path."""
+    if count_eps is None:
+        count_eps = eps
+    x, ldx = _row_major(x)
+    dy, ldy = _row_major(dy)
+    _chk(x), _chk(dy)
+    n, C = x.shape
+    dev = x.device
+    mean = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
+    rstd = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
+    sums = torch.empty(batch_size * C * 2, dtype=torch.float64, device=dev)
+    call('ofx_gn_stats', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
+    call('ofx_gn_finalize', ptr(sums), ptr(count), batch_size, C, groups, eps, count_eps, ptr(mean), ptr(rstd),
+         stream())
+    w = weight.detach().reshape(-1).contiguous()
+    b = bias.detach().reshape(-1).contiguous()
+    coef = torch.empty(batch_size * C * 3, dtype=torch.float32, device=dev)
+    dx = torch.empty(n, C, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    call('ofx_gn_backward', ptr(x), ldx, ptr(dy), ldy, n, C, ptr(batch_id), batch_size, ptr(count), groups, count_eps,
+         ptr(mean), ptr(rstd), ptr(w), ptr(b), ACT[act], ptr(sums), ptr(coef), ptr(dx), C, ptr(dgamma), ptr(dbeta),
+         stream())
+    return dx, dgamma, dbeta
+
+
 STATS_ATTR = '_ofx_gn_stats'
 
 

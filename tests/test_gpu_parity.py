@@ -338,6 +338,38 @@ def test_graphconv_backward_vs_autograd():
         close(dW, W64.grad.float(), 1e-5)
 
 
+def test_group_norm_backward_vs_autograd():
+    """DualOctreeGroupNorm (+SiLU / GELU) backward against torch.autograd of the fp64 oracle norm, ragged batch."""
+    import torch.nn.functional as F
+    from octfusion_amd import ops
+    from oracle import dual_octree as OD, modules as OM, sampler as OS
+    split = C.random_split_small(4, 3, 52, p=0.4)
+    split[2] = -1.0
+    oc, doc = small(split)
+    o_doc = OD.OracleDualOctree(OS.split2octree_small(split, 5, 3))
+    o_doc.post_processing_for_docnn()
+    for d, Cc, act in [(5, 64, None), (4, 128, 'silu'), (5, 24, 'gelu'), (5, 96, 'silu')]:
+        N = doc.csr(d)[2]
+        groups = OM.gn_groups(Cc)
+        x = C.rand_input('gbx%d_%d' % (d, Cc), N, Cc) * 1.5 + 0.3
+        dy = C.rand_input('gbdy%d_%d' % (d, Cc), N, Cc)
+        w = C.rand_input('gbw%d' % Cc, 1, Cc) * 0.5 + 1.0
+        b = C.rand_input('gbb%d' % Cc, 1, Cc) * 0.2
+        with torch.enable_grad():
+            x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+            y = OM.dual_octree_group_norm(x64, o_doc, d, w64, b64, 32)
+            if act == 'silu':
+                y = F.silu(y)
+            elif act == 'gelu':
+                y = F.gelu(y)
+            (y * dy.double()).sum().backward()
+        dx, dg, db = ops.group_norm_backward(x.to(dev()), dy.to(dev()), doc.batch_id32(d), doc.count(d), doc.batch_size,
+                                             w.to(dev()), b.to(dev()), groups, act=act)
+        close(dx, x64.grad.float(), 2e-5)
+        close(dg, w64.grad.float().reshape(-1), 2e-5)
+        close(db, b64.grad.float().reshape(-1), 2e-5)
+
+
 def to_rows(vox, depth):
     from octfusion_amd import ops
     return ops.voxel2octree_cf(vox.to(dev()).contiguous(), depth)

@@ -49,5 +49,9 @@ for d, cin, cout in [(6, 128, 128), (6, 256, 256), (5, 256, 256), (4, 512, 512)]
     A = torch.randn(N, 7 * cin, device=dev)
     pw = ops.PackedWeight().get(torch.randn(7 * cin, cout, device=dev), 'kn')
     t_dense = timeit(lambda: ops.gemm(A, pw))
+    dyy = torch.randn(N, cout, device=dev)
+    t_dx = timeit(lambda: ops.graphconv_backward(x, dyy, doc, d, conv.weights, d - 1, need_dw=False), n=10)
+    t_dw = timeit(lambda: ops.graphconv_backward(x, dyy, doc, d, conv.weights, d - 1, need_dx=False), n=10)
+    print('   backward: dx %.3f ms (%.0f TF)  dW %.3f ms (%.0f TF)' % (t_dx, 2.0 * N * 7 * cin * cout / t_dx / 1e9, t_dw, flops / t_dw / 1e9))
     print('d%d N=%d cin=%d cout=%d: graph %.3f ms (%.0f TF)  no-stats %.3f ms  self-gather %.3f ms  random-gather %.3f ms  dense %.3f ms (%.0f TF)'
           % (d, N, cin, cout, t, flops / t / 1e9, t_nostats, t_self, t_rnd, t_dense, 2.0 * N * 7 * cin * cout / t_dense / 1e9))

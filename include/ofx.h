@@ -174,6 +174,10 @@ int ofx_gn_backward(const float* x, int64_t ldx, const float* dy, int64_t ldy, i
                     const int32_t* batch_id, int batch_size, const float* count, int groups, float count_eps,
                     const float* mean, const float* rstd, const float* w, const float* bias, int act, double* sums,
                     float* coef, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* stream);
+/* out [K, N] = P^T Q for row-major P [rows, K], Q [rows, N] (weight gradients of the dense layers: dW = x^T dy).
+ * K, N multiples of 4; exact fp32 MFMA, slice-ordered (deterministic) reduction of the partials held in ws. */
+int ofx_gemm_tn_f32(const float* P, int64_t ldp, const float* Q, int64_t ldq, int64_t rows, int64_t K, int64_t N,
+                    float* out, void* ws, size_t ws_bytes, void* stream);
 /* NeuralMPU SDF evaluation -- replaces NeuralMPU.__call__ / get_linear_pred / octree_linear_pts
  * (models/networks/dualoctree_networks/mpu.py:55-153), spmm / modulated_spmm (utils/spmm.py:12-61) and, with the
  * _grid entry, the sampling loop of calc_sdf (utils/util_dualoctree.py:99-118).

@@ -1721,6 +1721,36 @@ extern "C" int ofx_graphconv_bwd_weight(const float* x, int64_t ldx, int cin, in
   return OFX_OK;
 }
 
+// out[K, N] = P^T @ Q for row-major P [rows, K], Q [rows, N] (the weight gradient of every Linear / Conv1x1 /
+// pool / unpool layer: dW = x^T dy).  Exact fp32 MFMA, deterministic.  ws: slices * K * N floats of partials.
+extern "C" int ofx_gemm_tn_f32(const float* P, int64_t ldp, const float* Q, int64_t ldq, int64_t rows, int64_t K,
+                               int64_t N, float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (rows < 0 || K < 4 || N < 4 || (K & 3) || (N & 3) || !out || !ws || ldp < K || ldq < N || ((ldp | ldq) & 3) ||
+      (rows > 0 && (!P || !Q)) || (((uintptr_t)P | (uintptr_t)Q | (uintptr_t)ws) & 15))
+    return OFX_EINVAL;
+  hipStream_t st = ofx_stream(stream);
+  const int64_t total = K * N;
+  if (rows == 0) {
+    if (hipMemsetAsync(out, 0, (size_t)total * sizeof(float), st) != hipSuccess) return OFX_ELAUNCH;
+    return OFX_OK;
+  }
+  const int tiles = (int)(ofx_cdiv(K, 128) * ofx_cdiv(N, 128));
+  int slices = (int)ofx_cdiv(1024, tiles);
+  if (slices > 256) slices = 256;
+  if (slices > (int)ofx_cdiv(rows, 32)) slices = (int)ofx_cdiv(rows, 32);
+  while (slices > 1 && (size_t)slices * total * sizeof(float) > ws_bytes) --slices;
+  if ((size_t)slices * total * sizeof(float) > ws_bytes) return OFX_EINVAL;
+  TnArgs a = {};
+  a.P = P; a.ldp = ldp; a.Q = Q; a.ldq = ldq; a.Kp = K; a.N = N; a.Kf = K; a.rows = rows; a.row0 = 0;
+  a.rows_per_slice = ofx_cdiv(ofx_cdiv(rows, slices), 32) * 32;
+  slices = (int)ofx_cdiv(rows, a.rows_per_slice);
+  a.part = (float*)ws;
+  tn_gemm_kernel<true><<<dim3((unsigned)ofx_cdiv(K, 128), (unsigned)ofx_cdiv(N, 128), (unsigned)slices), 256, 0, st>>>(a);
+  tn_reduce_kernel<<<ofx_grid(total, 256), 256, 0, st>>>(a.part, slices, total, out, 0);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
 extern "C" int ofx_gridconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_in, int64_t n_out,
                                 const int32_t* nbr27, const int32_t* nbr27_ext, const float* zero_row,
                                 const float* Wp, int cout,

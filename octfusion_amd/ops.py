@@ -192,6 +192,26 @@ def graphconv(x, nbr, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None
     return out
 
 
+def gemm_tn(p, q):
+    """p^T @ q for row-major p [rows, K], q [rows, N] (dense weight gradients: dW = x^T dy)."""
+    p, ldp = _row_major(p)
+    q, ldq = _row_major(q)
+    _chk(p), _chk(q)
+    assert p.shape[0] == q.shape[0]
+    K, N = p.shape[1], q.shape[1]
+    out = torch.empty(K, N, dtype=torch.float32, device=p.device)
+    ws = workspace(p.device)
+    call('ofx_gemm_tn_f32', ptr(p), ldp, ptr(q), ldq, p.shape[0], K, N, ptr(out), ptr(ws), ws.numel(), stream())
+    return out
+
+
+def linear_backward(x, dy, weight, need_dx=True):
+    """y = x @ weight^T + bias (nn.Linear / Conv1x1, weight [out, in]): returns (dx, dW [out, in], dbias [out])."""
+    dW = gemm_tn(dy, x)
+    dx = gemm(dy, PackedWeight().get(weight, 'kn')) if need_dx else None        # dy [n, out] @ W [out, in]
+    return dx, dW, dy.sum(0)
+
+
 def graphconv_backward(x, dy, doctree, d, weights, n_node_type, need_dx=True, need_dw=True):
     """Gradients of y = GraphConv(x) (modules.py:194-220) w.r.t. x and the weights, given dy = dL/dy.
     Returns (dx [N, Cin] or None, dW [7*(Cin+nt'), Cout] or None) -- training path, SURVEY 8f-4."""

@@ -370,6 +370,19 @@ def test_group_norm_backward_vs_autograd():
         close(db, b64.grad.float().reshape(-1), 2e-5)
 
 
+def test_dense_backward_pieces():
+    """gemm_tn (P^T Q on the fp32 MFMA, slice-ordered reduce) and the Linear / Conv1x1 backward built on it."""
+    from octfusion_amd import ops
+    for rows, K, N in [(1000, 64, 128), (33, 132, 4), (5000, 8, 260), (1, 4, 4)]:
+        P, Q = torch.randn(rows, K), torch.randn(rows, N)
+        close(ops.gemm_tn(P.to(dev()), Q.to(dev())), (P.double().t() @ Q.double()).float(), 1e-5)
+    x, dy, W = torch.randn(777, 96), torch.randn(777, 40), torch.randn(40, 96)
+    dx, dW, db = ops.linear_backward(x.to(dev()), dy.to(dev()), W.to(dev()))
+    close(dx, (dy.double() @ W.double()).float(), 1e-4)
+    close(dW, (dy.double().t() @ x.double()).float(), 1e-5)
+    close(db, dy.sum(0), 1e-5)
+
+
 def to_rows(vox, depth):
     from octfusion_amd import ops
     return ops.voxel2octree_cf(vox.to(dev()).contiguous(), depth)

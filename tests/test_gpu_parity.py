@@ -383,6 +383,39 @@ def test_dense_backward_pieces():
     close(db, dy.sum(0), 1e-5)
 
 
+def test_resblock_backward_vs_autograd():
+    """Whole GraphResBlockEmbed backward (norm+SiLU, GraphConv + time embedding, norm+SiLU, GraphConv, skip 1x1)
+    assembled from the gradient kernels, against torch.autograd through the fp64 oracle block."""
+    from octfusion_amd import modules as M, backward as BW
+    from oracle import dual_octree as OD, modules as OM, sampler as OS
+    split = C.random_split_small(3, 3, 53, p=0.45)
+    oc, doc = small(split)
+    o_doc = OD.OracleDualOctree(OS.split2octree_small(split, 5, 3))
+    o_doc.post_processing_for_docnn()
+    for d, cin, cout in [(5, 64, 96), (4, 64, 64)]:
+        blk = M.GraphResBlockEmbed(cin, 48, 0.0, cout, 7, 7, d - 1)
+        sd = C.fill_state_dict([(k, tuple(v.shape)) for k, v in blk.state_dict().items()])
+        sd['conv2.weights'] = C.rand_input('rb_c2_%d' % cout, *sd['conv2.weights'].shape) * 0.05    # not the zero init
+        blk.load_state_dict(sd)
+        blk = blk.to(dev())
+        N = doc.csr(d)[2]
+        x = C.rand_input('rbx%d' % d, N, cin)
+        emb = C.rand_input('rbe%d' % d, 3, 48)
+        dy = C.rand_input('rbdy%d' % d, N, cout)
+        with torch.enable_grad():
+            sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+            x64, e64 = x.double().requires_grad_(True), emb.double().requires_grad_(True)
+            y = OM.graph_resblock_embed(x64, e64, o_doc, d, sd64, d - 1)
+            (y * dy.double()).sum().backward()
+        close(blk(x.to(dev()), emb.to(dev()), doc, d), y.detach().float(), 1e-4)
+        dx, demb, grads = BW.graph_resblock_embed_backward(blk, x.to(dev()), emb.to(dev()), doc, d, dy.to(dev()))
+        close(dx, x64.grad.float(), 2e-4)
+        close(demb, e64.grad.float(), 2e-4)
+        assert set(grads) == set(sd)
+        for k, gval in grads.items():
+            close(gval, sd64[k].grad.float(), 2e-4)
+
+
 def to_rows(vox, depth):
     from octfusion_amd import ops
     return ops.voxel2octree_cf(vox.to(dev()).contiguous(), depth)

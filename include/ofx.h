@@ -178,6 +178,27 @@ int ofx_gn_backward(const float* x, int64_t ldx, const float* dy, int64_t ldy, i
  * K, N multiples of 4; exact fp32 MFMA, slice-ordered (deterministic) reduction of the partials held in ws. */
 int ofx_gemm_tn_f32(const float* P, int64_t ldp, const float* Q, int64_t ldq, int64_t rows, int64_t K, int64_t N,
                     float* out, void* ws, size_t ws_bytes, void* stream);
+/* Reverse tables for any tap table (the dense layers' 27-tap grid tables): nbr [n_out, ndir], valid sources in
+ * [0, n_in); reverse CSR keyed by (source row, tap) with unit weights; and segment-generic versions of the
+ * weighted table builders (nseg segments, sources in [0, n_src)). */
+int ofx_table_reverse_count(const int32_t* nbr, int64_t n_out, int ndir, int64_t n_in, int32_t* rev_cnt, void* stream);
+int ofx_table_reverse_fill(const int32_t* nbr, int64_t n_out, int ndir, int64_t n_in, const int32_t* rev_ptr,
+                           int32_t* cursor, int32_t* rev_row, float* rev_w, void* stream);
+int ofx_seg_primary_w(const int32_t* seg_ptr, const int32_t* col, const float* w, int64_t nseg, int32_t* nbr,
+                      void* stream);
+int ofx_seg_multi_flag_w(const int32_t* seg_ptr, const float* w, int64_t nseg, int32_t* flag, void* stream);
+int ofx_seg_primary_ext_w(const int32_t* seg_ptr, const int32_t* col, const float* w, int64_t nseg, int64_t n_src,
+                          const int32_t* rank, int32_t* nbr_ext, int32_t* multi_seg, void* stream);
+/* Backward of the 27-tap grid convolution (torch autograd of nn.Conv3d(k=3, padding=1[, stride 2]) and of
+ * nearest-upsample + conv: graph_unet_lr.py / modules.py:63-95).  WpT = ofx_pack_conv3d of weight.transpose(0,1);
+ * dWp [pad32(27*cin), cout], row k = tap*cin + c. */
+int ofx_gridconv_bwd_data(const float* dy, int64_t ldy, int cout, int64_t n_out, int64_t n_in, const int32_t* nbr_rev,
+                          const int32_t* rev_ptr, const int32_t* rev_row, const float* rev_w,
+                          const int32_t* nbr_ext_rev, const int32_t* multi_seg, int64_t n_multi, float* aux,
+                          const float* WpT, int cin, float* dx, int64_t ldx, void* ws, size_t ws_bytes, void* stream);
+int ofx_gridconv_bwd_weight(const float* x, int64_t ldx, int cin, int64_t n_in, int64_t n_out, const int32_t* nbr27,
+                            const int32_t* nbr27_ext, const float* zero_row, const float* dy, int64_t ldy, int cout,
+                            float* dWp, void* ws, size_t ws_bytes, void* stream);
 /* NeuralMPU SDF evaluation -- replaces NeuralMPU.__call__ / get_linear_pred / octree_linear_pts
  * (models/networks/dualoctree_networks/mpu.py:55-153), spmm / modulated_spmm (utils/spmm.py:12-61) and, with the
  * _grid entry, the sampling loop of calc_sdf (utils/util_dualoctree.py:99-118).

@@ -57,6 +57,14 @@ _SIGS = {
     'ofx_gn_backward': (c_i, [c_p, c_l, c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_p,
                               c_p, c_l, c_p, c_p, c_p], True),
     'ofx_gemm_tn_f32': (c_i, [c_p, c_l, c_p, c_l, c_l, c_l, c_l, c_p, c_p, c_sz, c_p], True),
+    'ofx_table_reverse_count': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p], True),
+    'ofx_table_reverse_fill': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_p], True),
+    'ofx_seg_primary_w': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p], True),
+    'ofx_seg_multi_flag_w': (c_i, [c_p, c_p, c_l, c_p, c_p], True),
+    'ofx_seg_primary_ext_w': (c_i, [c_p, c_p, c_p, c_l, c_l, c_p, c_p, c_p, c_p], True),
+    'ofx_gridconv_bwd_data': (c_i, [c_p, c_l, c_i, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_l,
+                                    c_p, c_sz, c_p], True),
+    'ofx_gridconv_bwd_weight': (c_i, [c_p, c_l, c_i, c_l, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_sz, c_p], True),
     'ofx_mpu_eval': (c_i, [ctypes.POINTER(OfxTree), c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p], True),
     'ofx_mpu_eval_grid': (c_i, [ctypes.POINTER(OfxTree), c_i, c_i, c_p, c_i, c_f, c_f, c_i, c_l, c_l, c_p, c_p, c_p], True),
     'ofx_graph_fill': (c_i, [ctypes.POINTER(OfxTree), c_i, c_p, c_p, c_p], True),

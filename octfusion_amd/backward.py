@@ -56,3 +56,37 @@ def graph_resblock_embed_backward(blk, x, emb, doctree, depth, dy):
             grads['skip_connection.linear.bias'] = dbs
         dx += dxs
     return dx, demb, grads
+
+
+@torch.no_grad()
+def gridconv_backward(conv, x, dy, gs, need_dx=True):
+    """Gradients of y = GridConv3d(x) (nn.Conv3d 3^3, stride 1 / stride 2 / nearest-upsample + conv, in node-row
+    layout) given dy: (dx [n_in, cin], dweight [cout, cin, 3, 3, 3], dbias [cout])."""
+    from ._lib import call, ptr, stream, lib
+    x, ldx = ops._row_major(x)
+    dy, ldy = ops._row_major(dy)
+    cin, cout, mode = conv.in_channels, conv.out_channels, conv.mode
+    d_out = conv.out_depth(gs.depth)
+    n_in, n_out = x.shape[0], dy.shape[0]
+    assert n_out == gs.B * 8 ** d_out and dy.shape[1] == cout and x.shape[1] == cin
+    dev = x.device
+    ws = ops.workspace(dev)
+    dx = None
+    if need_dx:
+        rv = gs.cache.rev(mode, d_out)
+        wt = ops.PackedConv3d().get(conv.weight.detach().transpose(0, 1).contiguous())
+        dx = torch.empty(n_in, cin, dtype=torch.float32, device=dev)
+        fast = cout % 32 == 0 and ldy % 4 == 0
+        aux = torch.empty((rv['V'] + 1) * ldy, dtype=torch.float32, device=dev) if fast else None
+        call('ofx_gridconv_bwd_data', ptr(dy), ldy, cout, n_out, n_in, ptr(rv['nbr']), ptr(rv['rev_ptr']),
+             ptr(rv['rev_row']), ptr(rv['rev_w']), ptr(rv['nbr_ext']) if fast else None,
+             ptr(rv['multi_seg']) if fast else None, rv['V'] if fast else 0, ptr(aux), ptr(wt.t), cin, ptr(dx), cin,
+             ptr(ws), ws.numel(), stream())
+    Kp = lib().ofx_conv3d_packed_k(cin)
+    dwp = torch.empty(Kp, cout, dtype=torch.float32, device=dev)
+    fast = cin % 32 == 0 and ldx % 4 == 0
+    call('ofx_gridconv_bwd_weight', ptr(x), ldx, cin, n_in, n_out, None if fast else ptr(gs.cache.table(mode, d_out, False)),
+         ptr(gs.cache.table(mode, d_out, True)) if fast else None, ptr(ops.zero_row(dev)) if fast else None,
+         ptr(dy), ldy, cout, ptr(dwp), ptr(ws), ws.numel(), stream())
+    dweight = dwp[:27 * cin].view(27, cin, cout).permute(2, 1, 0).reshape(cout, cin, 3, 3, 3).contiguous()
+    return dx, dweight, dy.sum(0)

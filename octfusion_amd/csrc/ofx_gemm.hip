@@ -1544,7 +1544,7 @@ extern "C" int ofx_graphconv_bwd_data(const float* dy, int64_t ldy, int cout, in
 // slice order (deterministic).
 struct TnArgs {
   const float* P; int64_t ldp;              // DENSE_P: col rows [rows, Kp]
-  const float* x; int64_t ldx; int cin;     // gathered P
+  const float* x; int64_t ldx; int cin; int ndir;   // gathered P (ndir source rows per node: 7 graph / 27 grid)
   const int32_t* nbr_ext; const float* aux; int64_t n_src;
   const float* tf; int64_t ldt; int64_t Kf;
   const float* Q; int64_t ldq;              // dy [rows, cout]
@@ -1585,9 +1585,9 @@ __global__ void __launch_bounds__(256, 2) tn_gemm_kernel(const TnArgs a) {
           v = *reinterpret_cast<const float4*>(a.P + row * a.ldp + m);
         } else if (m < a.Kf) {
           const int64_t kk = m;
-          if (kk < 7 * (int64_t)a.cin) {
+          if (kk < a.ndir * (int64_t)a.cin) {
             const int dir = (int)(kk / a.cin), c = (int)(kk - (int64_t)dir * a.cin);
-            const int64_t id = a.nbr_ext[(a.row0 + row) * 7 + dir];
+            const int64_t id = a.nbr_ext[(a.row0 + row) * a.ndir + dir];
             const float* src = id < a.n_src ? a.x + id * a.ldx : a.aux + (id - a.n_src) * a.ldx;
             v = *reinterpret_cast<const float4*>(src + c);
           }
@@ -1683,7 +1683,7 @@ extern "C" int ofx_graphconv_bwd_weight(const float* x, int64_t ldx, int cin, in
     if (slices > 256) slices = 256;
     while (slices > 1 && (size_t)slices * total * sizeof(float) > ws_bytes) --slices;
     if ((size_t)slices * total * sizeof(float) > ws_bytes) return OFX_EINVAL;
-    a.x = x; a.ldx = ldx; a.cin = cin; a.nbr_ext = nbr_ext; a.aux = aux; a.n_src = n_nodes;
+    a.x = x; a.ldx = ldx; a.cin = cin; a.ndir = 7; a.nbr_ext = nbr_ext; a.aux = aux; a.n_src = n_nodes;
     a.tf = type_frac ? type_frac : x; a.ldt = type_frac ? ldt : ldx;
     a.rows = n_nodes; a.row0 = 0;
     a.rows_per_slice = ofx_cdiv(ofx_cdiv(n_nodes, slices), 32) * 32;
@@ -1723,6 +1723,97 @@ extern "C" int ofx_graphconv_bwd_weight(const float* x, int64_t ldx, int cin, in
 
 // out[K, N] = P^T @ Q for row-major P [rows, K], Q [rows, N] (the weight gradient of every Linear / Conv1x1 /
 // pool / unpool layer: dW = x^T dy).  Exact fp32 MFMA, deterministic.  ws: slices * K * N floats of partials.
+// Backward of the 27-tap grid convolution (nn.Conv3d 3^3 of the dense lr net in node-row layout).
+// _bwd_data: dx [n_in, cin] = the same gather-GEMM over the reverse tap table (summing segments: stride-2 and
+//   upsample+conv taps fan in) with W^T per tap (WpT = ofx_pack_conv3d of weight.transpose(0, 1)).
+// _bwd_weight: dWp [pad32(27*cin), cout], row k = tap*cin + c, = col^T dy with col gathered through the forward
+//   table (padding taps name the zero row).
+extern "C" int ofx_gridconv_bwd_data(const float* dy, int64_t ldy, int cout, int64_t n_out, int64_t n_in,
+                                     const int32_t* nbr_rev, const int32_t* rev_ptr, const int32_t* rev_row,
+                                     const float* rev_w, const int32_t* nbr_ext_rev, const int32_t* multi_seg,
+                                     int64_t n_multi, float* aux, const float* WpT, int cin, float* dx, int64_t ldx,
+                                     void* ws, size_t ws_bytes, void* stream) {
+  if (n_in == 0 && cin >= 1 && cout >= 1) return OFX_OK;
+  GemmArgs g = {};
+  const int64_t KpT = ofx_conv3d_packed_k(cout);
+  int rc = gather_common(g, dy, ldy, cout, 27, n_in, nbr_rev, rev_ptr, rev_row, WpT, KpT, cin, nullptr, nullptr, 0,
+                         nullptr, nullptr, 0, dx, ldx);
+  if (rc) return rc;
+  if (!rev_ptr || !rev_row || !rev_w || n_out < 1) return OFX_EINVAL;
+  g.edge_w = rev_w;
+  g.tf = dy; g.ldt = ldy;
+  hipStream_t st = ofx_stream(stream);
+  if (g.fast && nbr_ext_rev && aux && (((uintptr_t)aux & 15) == 0)) {
+    if (n_multi < 0 || (n_multi > 0 && !multi_seg)) return OFX_EINVAL;
+    multi_mean_kernel<<<ofx_grid((n_multi + 1) * (cout / 4), 256), 256, 0, st>>>(dy, ldy, cout, rev_ptr, rev_row,
+                                                                                multi_seg, n_multi, aux, ldy, rev_w);
+    g.nbr_ext = nbr_ext_rev; g.aux = aux; g.ldaux = ldy; g.n_src = n_out;
+  } else {
+    rc = launch_gather_via_col(g, (float*)ws, ws_bytes, st);
+    if (rc >= 0) return rc;
+  }
+  return launch_gemm<MODE_GATHER>(g, (float*)ws, ws_bytes, st);
+}
+
+extern "C" int ofx_gridconv_bwd_weight(const float* x, int64_t ldx, int cin, int64_t n_in, int64_t n_out,
+                                       const int32_t* nbr27, const int32_t* nbr27_ext, const float* zero_row,
+                                       const float* dy, int64_t ldy, int cout, float* dWp, void* ws, size_t ws_bytes,
+                                       void* stream) {
+  if (n_in < 1 || n_out < 0 || cin < 1 || cout < 1 || (cout & 3) || !x || !dy || !dWp || !ws || ldy < cout ||
+      (ldy & 3) || ldx < cin || (((uintptr_t)dy | (uintptr_t)ws) & 15))
+    return OFX_EINVAL;
+  const int64_t Kp = ofx_conv3d_packed_k(cin), total = Kp * cout;
+  hipStream_t st = ofx_stream(stream);
+  if (n_out == 0) {
+    if (hipMemsetAsync(dWp, 0, (size_t)total * sizeof(float), st) != hipSuccess) return OFX_ELAUNCH;
+    return OFX_OK;
+  }
+  const int tiles = (int)(ofx_cdiv(Kp, 128) * ofx_cdiv(cout, 128));
+  TnArgs a = {};
+  a.Q = dy; a.ldq = ldy; a.Kp = Kp; a.N = cout; a.Kf = Kp; a.part = (float*)ws;
+  const bool fast = (cin % 32 == 0) && ((ldx & 3) == 0) && (((uintptr_t)x & 15) == 0) && nbr27_ext && zero_row &&
+                    (((uintptr_t)zero_row & 15) == 0);
+  if (fast) {
+    int slices = (int)ofx_cdiv(1024, tiles);
+    if (slices > 256) slices = 256;
+    if (slices > (int)ofx_cdiv(n_out, 32)) slices = (int)ofx_cdiv(n_out, 32);
+    while (slices > 1 && (size_t)slices * total * sizeof(float) > ws_bytes) --slices;
+    if ((size_t)slices * total * sizeof(float) > ws_bytes) return OFX_EINVAL;
+    a.x = x; a.ldx = ldx; a.cin = cin; a.ndir = 27; a.nbr_ext = nbr27_ext; a.aux = zero_row; a.n_src = n_in;
+    a.tf = x; a.ldt = ldx; a.rows = n_out; a.row0 = 0;
+    a.rows_per_slice = ofx_cdiv(ofx_cdiv(n_out, slices), 32) * 32;
+    slices = (int)ofx_cdiv(n_out, a.rows_per_slice);
+    tn_gemm_kernel<false><<<dim3((unsigned)ofx_cdiv(Kp, 128), (unsigned)ofx_cdiv(cout, 128), (unsigned)slices), 256, 0, st>>>(a);
+    tn_reduce_kernel<<<ofx_grid(total, 256), 256, 0, st>>>(a.part, slices, total, dWp, 0);
+    OFX_LAUNCH_CHECK();
+    return OFX_OK;
+  }
+  if (!nbr27) return OFX_EINVAL;
+  GemmArgs g = {};
+  g.x = x; g.ldx = ldx; g.cin = cin; g.ndir = 27; g.nbr = nbr27; g.tf = x; g.ldt = ldx; g.Kf = Kp; g.Kp = Kp; g.M = n_out;
+  int slices = (int)ofx_cdiv(512, tiles);
+  if (slices > 64) slices = 64;
+  const size_t part_bytes = ((size_t)slices * total * sizeof(float) + 255) & ~size_t(255);
+  if (part_bytes >= ws_bytes) return OFX_EINVAL;
+  int64_t chunk = (int64_t)((ws_bytes - part_bytes) / ((size_t)Kp * sizeof(float))) / 32 * 32;
+  if (chunk < 32) return OFX_EINVAL;
+  float* colbuf = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + part_bytes);
+  a.P = colbuf; a.ldp = Kp;
+  int first = 1;
+  for (int64_t r0 = 0; r0 < n_out; r0 += chunk) {
+    const int64_t rows = n_out - r0 < chunk ? n_out - r0 : chunk;
+    col_rows_kernel<<<ofx_grid(rows * (Kp >> 2), 256), 256, 0, st>>>(g, r0, rows, colbuf);
+    a.Q = dy + r0 * ldy; a.rows = rows; a.row0 = r0;
+    a.rows_per_slice = ofx_cdiv(ofx_cdiv(rows, slices), 32) * 32;
+    const int sl = (int)ofx_cdiv(rows, a.rows_per_slice);
+    tn_gemm_kernel<true><<<dim3((unsigned)ofx_cdiv(Kp, 128), (unsigned)ofx_cdiv(cout, 128), (unsigned)sl), 256, 0, st>>>(a);
+    tn_reduce_kernel<<<ofx_grid(total, 256), 256, 0, st>>>(a.part, sl, total, dWp, first ? 0 : 1);
+    first = 0;
+  }
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
 extern "C" int ofx_gemm_tn_f32(const float* P, int64_t ldp, const float* Q, int64_t ldq, int64_t rows, int64_t K,
                                int64_t N, float* out, void* ws, size_t ws_bytes, void* stream) {
   if (rows < 0 || K < 4 || N < 4 || (K & 3) || (N & 3) || !out || !ws || ldp < K || ldq < N || ((ldp | ldq) & 3) ||

@@ -646,3 +646,69 @@ extern "C" int ofx_graph_primary_ext_w(const int32_t* seg_ptr, const int32_t* co
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
+
+// ---- the same machinery for any segment structure (27-tap grid tables of the dense layers) -----------------
+// Dense tap table nbr[r, t] (valid source row in [0, n_in), anything else = padding) -> reverse CSR keyed by
+// (source row, tap), all weights 1.
+__global__ void tab_rev_count_kernel(const int32_t* __restrict__ nbr, int64_t total, int ndir, int64_t n_in,
+                                     int32_t* __restrict__ rcnt) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t s = nbr[e];
+    if (s >= 0 && s < n_in) atomicAdd(&rcnt[(int64_t)s * ndir + (int)(e % ndir)], 1);
+  }
+}
+__global__ void tab_rev_fill_kernel(const int32_t* __restrict__ nbr, int64_t total, int ndir, int64_t n_in,
+                                    const int32_t* __restrict__ rev_ptr, int32_t* __restrict__ cursor,
+                                    int32_t* __restrict__ rev_row, float* __restrict__ rev_w) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t s = nbr[e];
+    if (s < 0 || s >= n_in) continue;
+    const int64_t key = (int64_t)s * ndir + (int)(e % ndir);
+    const int32_t pos = rev_ptr[key] + atomicAdd(&cursor[key], 1);
+    rev_row[pos] = (int32_t)(e / ndir);
+    rev_w[pos] = 1.0f;
+  }
+}
+extern "C" int ofx_table_reverse_count(const int32_t* nbr, int64_t n_out, int ndir, int64_t n_in, int32_t* rev_cnt,
+                                       void* stream) {
+  if (!nbr || !rev_cnt || n_out < 0 || n_in < 0 || ndir < 1) return OFX_EINVAL;
+  if (n_in == 0) return OFX_OK;
+  if (hipMemsetAsync(rev_cnt, 0, (size_t)n_in * ndir * sizeof(int32_t), ofx_stream(stream)) != hipSuccess) return OFX_ELAUNCH;
+  if (n_out > 0)
+    tab_rev_count_kernel<<<ofx_grid(n_out * ndir, 256), 256, 0, ofx_stream(stream)>>>(nbr, n_out * ndir, ndir, n_in, rev_cnt);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+extern "C" int ofx_table_reverse_fill(const int32_t* nbr, int64_t n_out, int ndir, int64_t n_in, const int32_t* rev_ptr,
+                                      int32_t* cursor, int32_t* rev_row, float* rev_w, void* stream) {
+  if (!nbr || !rev_ptr || !cursor || !rev_row || !rev_w || n_out < 0 || n_in < 0 || ndir < 1) return OFX_EINVAL;
+  if (n_in == 0 || n_out == 0) return OFX_OK;
+  hipStream_t st = ofx_stream(stream);
+  if (hipMemsetAsync(cursor, 0, (size_t)n_in * ndir * sizeof(int32_t), st) != hipSuccess) return OFX_ELAUNCH;
+  tab_rev_fill_kernel<<<ofx_grid(n_out * ndir, 256), 256, 0, st>>>(nbr, n_out * ndir, ndir, n_in, rev_ptr, cursor, rev_row, rev_w);
+  rev_sort_kernel<<<ofx_grid(n_in * ndir, 256), 256, 0, st>>>(rev_ptr, n_in * ndir, rev_row, rev_w);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+extern "C" int ofx_seg_primary_w(const int32_t* seg_ptr, const int32_t* col, const float* w, int64_t nseg, int32_t* nbr,
+                                 void* stream) {
+  if (!seg_ptr || !nbr || nseg < 0) return OFX_EINVAL;
+  graph_primary_w_kernel<<<ofx_grid(nseg, 256), 256, 0, ofx_stream(stream)>>>(seg_ptr, col, w, nseg, nbr);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+extern "C" int ofx_seg_multi_flag_w(const int32_t* seg_ptr, const float* w, int64_t nseg, int32_t* flag, void* stream) {
+  if (!seg_ptr || !flag || nseg < 0) return OFX_EINVAL;
+  graph_multi_flag_w_kernel<<<ofx_grid(nseg, 256), 256, 0, ofx_stream(stream)>>>(seg_ptr, w, nseg, flag);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+extern "C" int ofx_seg_primary_ext_w(const int32_t* seg_ptr, const int32_t* col, const float* w, int64_t nseg,
+                                     int64_t n_src, const int32_t* rank, int32_t* nbr_ext, int32_t* multi_seg,
+                                     void* stream) {
+  if (!seg_ptr || !rank || !nbr_ext || nseg < 0) return OFX_EINVAL;
+  graph_primary_ext_w_kernel<<<ofx_grid(nseg, 256), 256, 0, ofx_stream(stream)>>>(seg_ptr, col, w, nseg, n_src, rank,
+                                                                                nbr_ext, multi_seg);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}

@@ -57,6 +57,40 @@ class _GridCache:
             self._tab[k] = ops.grid_conv_table(mode, depth_out, self.B, self.device, pad)
         return self._tab[k]
 
+    def rev(self, mode, depth_out):
+        """Reverse tap tables of (mode, depth_out) for the backward pass of the 27-tap conv (ofx.h)."""
+        k = ('rev', mode, depth_out)
+        if k not in self._tab:
+            from ._lib import call, ptr, stream, lib
+            d_in = depth_out + (0, 1, -1)[mode]
+            n_in, n_out = self.B * 8 ** d_in, self.B * 8 ** depth_out
+            tab = self.table(mode, depth_out, False)
+            dev = self.device
+            nseg = n_in * 27
+            cnt = torch.empty(nseg, dtype=torch.int32, device=dev)
+            call('ofx_table_reverse_count', ptr(tab), n_out, 27, n_in, ptr(cnt), stream())
+            rev_ptr = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
+            ws = torch.empty(lib().ofx_scan_ws_bytes(nseg), dtype=torch.uint8, device=dev)
+            call('ofx_scan_i32', ptr(cnt), ptr(rev_ptr), nseg, ptr(ws), stream())
+            E = int(rev_ptr[-1].item())
+            rev_row = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+            rev_w = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+            call('ofx_table_reverse_fill', ptr(tab), n_out, 27, n_in, ptr(rev_ptr), ptr(cnt), ptr(rev_row), ptr(rev_w),
+                 stream())
+            nbr = torch.empty(nseg, dtype=torch.int32, device=dev)
+            call('ofx_seg_primary_w', ptr(rev_ptr), ptr(rev_row), ptr(rev_w), nseg, ptr(nbr), stream())
+            call('ofx_seg_multi_flag_w', ptr(rev_ptr), ptr(rev_w), nseg, ptr(cnt), stream())
+            rank = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
+            call('ofx_scan_i32', ptr(cnt), ptr(rank), nseg, ptr(ws), stream())
+            V = int(rank[-1].item())
+            nbr_ext = torch.empty(nseg, dtype=torch.int32, device=dev)
+            multi_seg = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
+            call('ofx_seg_primary_ext_w', ptr(rev_ptr), ptr(rev_row), ptr(rev_w), nseg, n_out, ptr(rank), ptr(nbr_ext),
+                 ptr(multi_seg), stream())
+            self._tab[k] = dict(rev_ptr=rev_ptr, rev_row=rev_row, rev_w=rev_w, nbr=nbr, nbr_ext=nbr_ext,
+                                multi_seg=multi_seg, V=V, n_in=n_in, n_out=n_out)
+        return self._tab[k]
+
     def batch_id(self, depth):
         if depth not in self._bid:
             per = 8 ** depth

@@ -308,6 +308,11 @@ int ofx_gridconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_in, int64_t
 int ofx_attention(const float* qkv, int64_t ldq, int batch_size, int T, int heads, int ch,
                   float* out, int64_t ldo, void* stream);
 
+/* Backward of ofx_attention (autograd of QKVAttention, modules.py:538-547): dqkv [rows, 3*C] in the layout of
+ * qkv, from dout [rows, C].  rowstat: scratch of batch*heads*T*3 floats.  T <= 512. */
+int ofx_attention_bwd(const float* qkv, int64_t ldq, const float* dout, int64_t ldo, int batch_size, int T, int heads,
+                      int ch, float* rowstat, float* dqkv, int64_t ldd, void* stream);
+
 /* Stand-alone segment-mean gather: col_data[r, dir, :] (the reference's
  * `scatter_mean(x[col], row*7+dir)`, modules.py:208-210).  HBM-bound; used for
  * the gather roofline measurement and as a building block. */

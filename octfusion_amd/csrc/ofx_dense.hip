@@ -215,3 +215,123 @@ extern "C" int ofx_attention(const float* qkv, int64_t ldq, int batch_size, int 
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
+
+// ---------------------------------------------------------------------------------
+// Backward of QKVAttention (training path; autograd of modules.py:538-547).  Per (batch element, head), with
+// S = ch^-1/2 * Q K^T, P = softmax_rows(S), O = P V and g = dL/dO:
+//   dP = g V^T,  D_i = sum_j P_ij dP_ij,  dS = P * (dP - D),  dQ = ch^-1/2 dS K,  dK = ch^-1/2 dS^T Q,  dV = P^T g.
+// The problem is tiny (T <= 512 tokens, 4 heads, batch 8): two plain fp32 kernels, one wave per query row
+// (row max / sum / D, dQ) and one wave per key row (dK, dV, recomputing P from the saved row statistics);
+// deterministic, no atomics.  Same row layout as the forward kernel.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__global__ void __launch_bounds__(256) attention_bwd_q_kernel(const float* __restrict__ qkv, int64_t ldq,
+                                                              const float* __restrict__ dout, int64_t ldo, int T,
+                                                              int heads, int ch, float* __restrict__ rowstat,
+                                                              float* __restrict__ dqkv, int64_t ldd) {
+  extern __shared__ float lds[];                      // [4 waves][T]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int i = blockIdx.x * 4 + wid;
+  if (i >= T) return;
+  float* ds = lds + wid * T;
+  const float sc = rsqrtf((float)ch);
+  const int64_t row0 = (int64_t)b * T;
+  const float* qi = qkv + (row0 + i) * ldq + (int64_t)hd * 3 * ch;
+  const float* gi = dout + (row0 + i) * ldo + (int64_t)hd * ch;
+  const float* kb = qkv + row0 * ldq + (int64_t)hd * 3 * ch + ch;
+  const float* vb = kb + ch;
+  float s[8], dp[8];                                   // T <= 512: up to 8 keys per lane
+  float m = -3.0e38f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int j = lane + 64 * t;
+    s[t] = -3.0e38f; dp[t] = 0.f;
+    if (j < T) {
+      float a = 0.f, d = 0.f;
+      for (int c = 0; c < ch; ++c) { a += qi[c] * kb[(int64_t)j * ldq + c]; d += gi[c] * vb[(int64_t)j * ldq + c]; }
+      s[t] = a * sc; dp[t] = d;
+      m = fmaxf(m, s[t]);
+    }
+  }
+  m = wave_max(m);
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { const int j = lane + 64 * t; if (j < T) { s[t] = __expf(s[t] - m); l += s[t]; } }
+  l = wave_sum(l);
+  const float inv = 1.f / l;
+  float D = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { const int j = lane + 64 * t; if (j < T) { s[t] *= inv; D += s[t] * dp[t]; } }
+  D = wave_sum(D);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { const int j = lane + 64 * t; if (j < T) ds[j] = s[t] * (dp[t] - D); }
+  if (lane == 0) {
+    float* rs = rowstat + ((int64_t)bh * T + i) * 3;
+    rs[0] = m; rs[1] = inv; rs[2] = D;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // dq_i[c] = sc * sum_j dS_ij k_j[c]: lanes over channels (coalesced key rows)
+  for (int c = lane; c < ch; c += 64) {
+    float a = 0.f;
+    for (int j = 0; j < T; ++j) a += ds[j] * kb[(int64_t)j * ldq + c];
+    dqkv[(row0 + i) * ldd + (int64_t)hd * 3 * ch + c] = a * sc;
+  }
+}
+
+__global__ void __launch_bounds__(256) attention_bwd_kv_kernel(const float* __restrict__ qkv, int64_t ldq,
+                                                               const float* __restrict__ dout, int64_t ldo, int T,
+                                                               int heads, int ch, const float* __restrict__ rowstat,
+                                                               float* __restrict__ dqkv, int64_t ldd) {
+  extern __shared__ float lds[];                      // [4 waves][2][T]: P column, dS column
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int j = blockIdx.x * 4 + wid;
+  if (j >= T) return;
+  float* pc = lds + wid * 2 * T;
+  float* dc = pc + T;
+  const float sc = rsqrtf((float)ch);
+  const int64_t row0 = (int64_t)b * T;
+  const float* qb = qkv + row0 * ldq + (int64_t)hd * 3 * ch;
+  const float* kj = qb + (int64_t)j * ldq + ch;
+  const float* vj = kj + ch;
+  const float* gb = dout + row0 * ldo + (int64_t)hd * ch;
+  const float* rs = rowstat + (int64_t)bh * T * 3;
+  for (int i = lane; i < T; i += 64) {
+    float a = 0.f, d = 0.f;
+    for (int c = 0; c < ch; ++c) { a += qb[(int64_t)i * ldq + c] * kj[c]; d += gb[(int64_t)i * ldo + c] * vj[c]; }
+    const float p = __expf(a * sc - rs[i * 3]) * rs[i * 3 + 1];
+    pc[i] = p;
+    dc[i] = p * (d - rs[i * 3 + 2]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int c = lane; c < ch; c += 64) {
+    float dk = 0.f, dv = 0.f;
+    for (int i = 0; i < T; ++i) { dk += dc[i] * qb[(int64_t)i * ldq + c]; dv += pc[i] * gb[(int64_t)i * ldo + c]; }
+    float* o = dqkv + (row0 + j) * ldd + (int64_t)hd * 3 * ch;
+    o[ch + c] = dk * sc;
+    o[2 * ch + c] = dv;
+  }
+}
+
+extern "C" int ofx_attention_bwd(const float* qkv, int64_t ldq, const float* dout, int64_t ldo, int batch_size, int T,
+                                 int heads, int ch, float* rowstat, float* dqkv, int64_t ldd, void* stream) {
+  if (!qkv || !dout || !rowstat || !dqkv || batch_size < 1 || T < 1 || T > 512 || heads < 1 || ch < 1 ||
+      ldq < 3 * (int64_t)heads * ch || ldd < 3 * (int64_t)heads * ch || ldo < (int64_t)heads * ch)
+    return OFX_EINVAL;
+  hipStream_t st = ofx_stream(stream);
+  const dim3 grid((unsigned)((T + 3) / 4), (unsigned)(batch_size * heads));
+  attention_bwd_q_kernel<<<grid, 256, 4 * T * sizeof(float), st>>>(qkv, ldq, dout, ldo, T, heads, ch, rowstat, dqkv, ldd);
+  attention_bwd_kv_kernel<<<grid, 256, 8 * T * sizeof(float), st>>>(qkv, ldq, dout, ldo, T, heads, ch, rowstat, dqkv, ldd);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}

@@ -337,6 +337,20 @@ def attention(qkv, batch_size, T, heads, out=None):
     return out
 
 
+def attention_backward(qkv, dout, batch_size, T, heads):
+    """dqkv of out = attention(qkv) (QKVAttention) given dout -- training path."""
+    qkv, ldq = _row_major(qkv)
+    dout, ldo = _row_major(dout)
+    _chk(qkv), _chk(dout)
+    C = qkv.shape[1] // 3
+    ch = C // heads
+    dqkv = torch.empty(qkv.shape[0], 3 * C, dtype=torch.float32, device=qkv.device)
+    rowstat = torch.empty(batch_size * heads * T * 3, dtype=torch.float32, device=qkv.device)
+    call('ofx_attention_bwd', ptr(qkv), ldq, ptr(dout), ldo, batch_size, T, heads, ch, ptr(rowstat), ptr(dqkv), 3 * C,
+         stream())
+    return dqkv
+
+
 def gather_mean(x, seg_ptr, col):
     """col_data [N, 7, C]: the reference's scatter_mean(x[col], row*7+dir)."""
     x, ldx = _row_major(x)

@@ -484,6 +484,28 @@ def test_gridconv_backward_vs_autograd():
         close(db, b64.grad.float(), 1e-5)
 
 
+def test_attention_backward_vs_autograd():
+    """QKVAttention backward (dq, dk, dv) against torch.autograd of the reference formula in fp64; the forward of
+    the same inputs is checked on the way."""
+    import math
+    from octfusion_amd import ops
+    for B, T, heads, ch in [(2, 64, 4, 16), (1, 512, 4, 32), (3, 8, 2, 64), (2, 100, 1, 24)]:
+        Cc = heads * ch
+        qkv = C.rand_input('attb%d_%d' % (T, ch), B * T, 3 * Cc)
+        dout = C.rand_input('attbd%d_%d' % (T, ch), B * T, Cc)
+        with torch.enable_grad():
+            x = qkv.double().requires_grad_(True)
+            t = x.view(B, T, heads, 3, ch).permute(0, 2, 3, 4, 1)          # [B, heads, 3, ch, T]
+            q, k, v = t[:, :, 0], t[:, :, 1], t[:, :, 2]
+            scale = 1 / math.sqrt(math.sqrt(ch))
+            w = torch.softmax(torch.einsum('bhct,bhcs->bhts', q * scale, k * scale), dim=-1)
+            o = torch.einsum('bhts,bhcs->bhct', w, v)                        # [B, heads, ch, T]
+            out = o.permute(0, 3, 1, 2).reshape(B * T, Cc)
+            (out * dout.double()).sum().backward()
+        close(ops.attention(qkv.to(dev()), B, T, heads), out.detach().float(), 1e-4)
+        close(ops.attention_backward(qkv.to(dev()), dout.to(dev()), B, T, heads), x.grad.float(), 1e-4)
+
+
 def test_precision_modes_vs_oracle():
     """bf16x3 (default) and exact-fp32 contraction both meet the bar; bf16x3 stays ~1e-5 from fp32."""
     from octfusion_amd import modules as M, ops

@@ -90,3 +90,202 @@ def gridconv_backward(conv, x, dy, gs, need_dx=True):
          ptr(dy), ldy, cout, ptr(dwp), ptr(ws), ws.numel(), stream())
     dweight = dwp[:27 * cin].view(27, cin, cout).permute(2, 1, 0).reshape(cout, cin, 3, 3, 3).contiguous()
     return dx, dweight, dy.sum(0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Dense lr U-Net (graph_unet_lr.UNet3DModel) in node-row layout: forward with saved intermediates + backward.
+# Parameter gradients are returned under the module's state_dict key names.
+def _silu_grad(x):
+    s = torch.sigmoid(x)
+    return s * (1 + x * (1 - s))
+
+
+class _Grads(dict):
+    def add(self, name, g):
+        self[name] = self[name] + g if name in self else g
+
+
+def _gn32_bwd(norm, x, dy, gs, act, G, prefix):
+    dx, dg, db = ops.group_norm_backward(x, dy, gs.cache.batch_id(gs.depth), gs.cache.count(gs.depth), gs.B, norm.weight,
+                                         norm.bias, norm.num_groups, norm.eps, act=act, count_eps=0.0)
+    G.add(prefix + 'weight', dg)
+    G.add(prefix + 'bias', db)
+    return dx
+
+
+def _conv_bwd(conv, x, dy, gs, G, prefix, need_dx=True):
+    dx, dw, db = gridconv_backward(conv, x, dy, gs, need_dx=need_dx)
+    G.add(prefix + 'weight', dw)
+    G.add(prefix + 'bias', db)
+    return dx
+
+
+def _point_bwd(m, x, dy, G, prefix):
+    w2 = m.weight.view(m.weight.shape[0], m.weight.shape[1])
+    dx, dw, db = ops.linear_backward(x, dy, w2)
+    G.add(prefix + 'weight', dw.view_as(m.weight))
+    G.add(prefix + 'bias', db)
+    return dx
+
+
+def _linear_bwd(m, x, dy, G, prefix):
+    dx, dw, db = ops.linear_backward(x, dy, m.weight)
+    G.add(prefix + 'weight', dw)
+    if m.bias is not None:
+        G.add(prefix + 'bias', db)
+    return dx
+
+
+def _resnet_fwd(blk, x, emb_act, gs):
+    h1 = blk.block1[0](x, gs, act='silu')
+    t = blk.time_mlp[1](emb_act)
+    c1 = blk.block1[2](h1, gs, emb=t)
+    h2 = blk.block2[0](c1, gs, act='silu')
+    skip = x if isinstance(blk.res_conv, nn.Identity) else blk.res_conv(x)
+    y = blk.block2[3](h2, gs, res=skip)
+    return y, (x, h1, c1, h2, gs)
+
+
+def _resnet_bwd(blk, saved, emb_act, dy, G, prefix):
+    """returns (dx, d emb_act contribution)."""
+    x, h1, c1, h2, gs = saved
+    dh2 = _conv_bwd(blk.block2[3], h2, dy, gs, G, prefix + 'block2.3.')
+    dc1 = _gn32_bwd(blk.block2[0], c1, dh2, gs, 'silu', G, prefix + 'block2.0.')
+    dt = batch_sums(dc1, gs.cache.batch_id(gs.depth), gs.B)
+    demb = _linear_bwd(blk.time_mlp[1], emb_act, dt, G, prefix + 'time_mlp.1.')
+    dh1 = _conv_bwd(blk.block1[2], h1, dc1, gs, G, prefix + 'block1.2.')
+    dx = _gn32_bwd(blk.block1[0], x, dh1, gs, 'silu', G, prefix + 'block1.0.')
+    if isinstance(blk.res_conv, nn.Identity):
+        dx += dy
+    else:
+        dx += _point_bwd(blk.res_conv, x, dy, G, prefix + 'res_conv.')
+    return dx, demb
+
+
+def _attnseq_fwd(seq, x, gs):
+    a = seq[0](x, gs, act='silu')
+    blk = seq[2]
+    n = blk.norm(a, gs)
+    qkv = blk.qkv(n)
+    h = ops.attention(qkv, gs.B, 8 ** gs.depth, blk.num_heads)
+    y = blk.proj_out(h, res=a)
+    return y, (x, a, n, qkv, h, gs)
+
+
+def _attnseq_bwd(seq, saved, dy, G, prefix):
+    x, a, n, qkv, h, gs = saved
+    blk = seq[2]
+    dh = _point_bwd(blk.proj_out, h, dy, G, prefix + '2.proj_out.')
+    dqkv = ops.attention_backward(qkv, dh, gs.B, 8 ** gs.depth, blk.num_heads)
+    dn = _point_bwd(blk.qkv, n, dqkv, G, prefix + '2.qkv.')
+    da = _gn32_bwd(blk.norm, a, dn, gs, None, G, prefix + '2.norm.')
+    da += dy
+    return _gn32_bwd(seq[0], x, da, gs, 'silu', G, prefix + '0.')
+
+
+@torch.no_grad()
+def lr_unet_forward_backward(net, x_rows, batch_size, timesteps, dy_fn, label=None, as_middle=False):
+    """Forward of graph_unet_lr.UNet3DModel.forward_rows keeping what the backward needs, then the backward.
+    dy_fn(y) -> dL/dy (e.g. 2 (y - target) / numel for the MSE of octfusion_model_union.py:242-269).
+    Returns (y, dx_rows, {state_dict key: gradient})."""
+    import math
+    from .graph_unet_lr import GridState, our_Identity
+    gs = GridState(batch_size, net.full_depth, x_rows.device)
+    G = _Grads()
+    x_in = x_rows
+    x = x_rows if as_middle else net.input_emb(x_rows, gs)
+    # ---- time embedding (a few KB: torch elementwise + libofx linears)
+    tt = timesteps.float()[:, None]
+    w = net.time_pos_emb.weights
+    f = tt * w[None, :] * 2 * math.pi
+    pe = torch.cat((tt, f.sin(), f.cos()), dim=-1).contiguous()
+    e1 = net.time_emb[0](pe)
+    a1 = ops.act(e1, 'silu')
+    e2 = net.time_emb[2](a1)
+    if net.num_classes is not None:
+        e2 = e2 + net.label_emb(label)
+    emb_act = ops.act(e2, 'silu')
+    demb_act = torch.zeros_like(emb_act)
+    # ---- down path
+    tape = []
+    hs = []
+    for i, (resnet, attn, down) in enumerate(net.downs):
+        x, s_res = _resnet_fwd(resnet, x, emb_act, gs)
+        s_att = None
+        if not isinstance(attn, our_Identity):
+            x, s_att = _attnseq_fwd(attn, x, gs)
+        hs.append(x)
+        s_down = None
+        if not isinstance(down, our_Identity):
+            s_down = (x, gs)
+            x, gs = down(x, gs)
+        tape.append(('down', i, s_res, s_att, s_down))
+    x, s_m1 = _resnet_fwd(net.mid_block1, x, emb_act, gs)
+    s_ma = None
+    if not isinstance(net.mid_self_attn, our_Identity):
+        x, s_ma = _attnseq_fwd(net.mid_self_attn, x, gs)
+    x, s_m2 = _resnet_fwd(net.mid_block2, x, emb_act, gs)
+    up_tape = []
+    for i, (resnet, attn, up) in enumerate(net.ups):
+        skip = hs.pop()
+        c_left = x.shape[1]
+        x = torch.cat((x, skip), dim=1)
+        x, s_res = _resnet_fwd(resnet, x, emb_act, gs)
+        s_att = None
+        if not isinstance(attn, our_Identity):
+            x, s_att = _attnseq_fwd(attn, x, gs)
+        s_up = (x, gs)
+        x, gs = up(x, gs)
+        up_tape.append((i, s_res, s_att, s_up, c_left))
+    x_end = x
+    e = net.end[0](x_end, gs, act='silu')
+    y = e if as_middle else net.out(e, gs)
+    # ================================================================= backward
+    dy = dy_fn(y)
+    de = dy if as_middle else _conv_bwd(net.out, e, dy, gs, G, 'out.')
+    dx = _gn32_bwd(net.end[0], x_end, de, gs, 'silu', G, 'end.0.')
+    dskips = {}
+    n_down = len(net.downs)
+    for i, s_res, s_att, s_up, c_left in reversed(up_tape):
+        resnet, attn, up = net.ups[i]
+        xu, gsu = s_up
+        dx = _conv_bwd(up.conv, xu, dx, gsu, G, 'ups.%d.2.conv.' % i)
+        if s_att is not None:
+            dx = _attnseq_bwd(attn, s_att, dx, G, 'ups.%d.1.' % i)
+        dx, d = _resnet_bwd(resnet, s_res, emb_act, dx, G, 'ups.%d.0.' % i)
+        demb_act += d
+        dskips[n_down - 1 - i] = dx[:, c_left:].contiguous()       # ups pop the skips in reverse order
+        dx = dx[:, :c_left].contiguous()
+    dx, d = _resnet_bwd(net.mid_block2, s_m2, emb_act, dx, G, 'mid_block2.')
+    demb_act += d
+    if s_ma is not None:
+        dx = _attnseq_bwd(net.mid_self_attn, s_ma, dx, G, 'mid_self_attn.')
+    dx, d = _resnet_bwd(net.mid_block1, s_m1, emb_act, dx, G, 'mid_block1.')
+    demb_act += d
+    for kind, i, s_res, s_att, s_down in reversed(tape):
+        resnet, attn, down = net.downs[i]
+        if s_down is not None:
+            xd, gsd = s_down
+            dx = _conv_bwd(down.op, xd, dx, gsd, G, 'downs.%d.2.op.' % i)
+        if i in dskips:
+            dx = dx + dskips[i]
+        if s_att is not None:
+            dx = _attnseq_bwd(attn, s_att, dx, G, 'downs.%d.1.' % i)
+        dx, d = _resnet_bwd(resnet, s_res, emb_act, dx, G, 'downs.%d.0.' % i)
+        demb_act += d
+    if not as_middle:
+        gs0 = GridState(batch_size, net.full_depth, x_rows.device)
+        dx = _conv_bwd(net.input_emb, x_in, dx, gs0, G, 'input_emb.')
+    # ---- time embedding backward
+    de2 = demb_act * _silu_grad(e2)
+    if net.num_classes is not None:
+        gl = torch.zeros_like(net.label_emb.weight)
+        gl.index_add_(0, label, de2)
+        G.add('label_emb.weight', gl)
+    da1 = _linear_bwd(net.time_emb[2], a1, de2, G, 'time_emb.2.')
+    de1 = da1 * _silu_grad(e1)
+    dpe = _linear_bwd(net.time_emb[0], pe, de1, G, 'time_emb.0.')
+    half = w.shape[0]
+    dsin, dcos = dpe[:, 1:1 + half], dpe[:, 1 + half:]
+    G.add('time_pos_emb.weights', ((dsin * f.cos() - dcos * f.sin()) * tt * 2 * math.pi).sum(0))
+    return y, dx, dict(G)

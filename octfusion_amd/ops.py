@@ -194,10 +194,22 @@ def graphconv(x, nbr, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None
 
 def gemm_tn(p, q):
     """p^T @ q for row-major p [rows, K], q [rows, N] (dense weight gradients: dW = x^T dy)."""
-    p, ldp = _row_major(p)
-    q, ldq = _row_major(q)
     _chk(p), _chk(q)
     assert p.shape[0] == q.shape[0]
+    K0, N0 = p.shape[1], q.shape[1]
+
+    def pad4(t):                       # odd widths (e.g. the 17-wide sinusoid embedding): zero-pad to 4 columns
+        c = t.shape[1]
+        if c % 4 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1 and t.data_ptr() % 16 == 0:
+            return t
+        out = torch.zeros(t.shape[0], (c + 3) // 4 * 4, dtype=torch.float32, device=t.device)
+        out[:, :c] = t
+        return out
+    p, q = pad4(p), pad4(q)
+    if (K0, N0) != (p.shape[1], q.shape[1]):
+        return gemm_tn(p, q)[:K0, :N0].contiguous()
+    p, ldp = _row_major(p)
+    q, ldq = _row_major(q)
     K, N = p.shape[1], q.shape[1]
     out = torch.empty(K, N, dtype=torch.float32, device=p.device)
     ws = workspace(p.device)

@@ -199,6 +199,11 @@ int ofx_gridconv_bwd_data(const float* dy, int64_t ldy, int cout, int64_t n_out,
 int ofx_gridconv_bwd_weight(const float* x, int64_t ldx, int cin, int64_t n_in, int64_t n_out, const int32_t* nbr27,
                             const int32_t* nbr27_ext, const float* zero_row, const float* dy, int64_t ldy, int cout,
                             float* dWp, void* ws, size_t ws_bytes, void* stream);
+/* Optimiser step of the training loop (octfusion_model_union.py:142, 478-487): torch.optim.AdamW's update
+ * (step >= 1 is the 1-based step count) and the EMA of the weights (ldm_diffusion_util.py:38-54). */
+int ofx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+int ofx_ema_update(float* ema, const float* param, int64_t n, float beta, void* stream);
 /* NeuralMPU SDF evaluation -- replaces NeuralMPU.__call__ / get_linear_pred / octree_linear_pts
  * (models/networks/dualoctree_networks/mpu.py:55-153), spmm / modulated_spmm (utils/spmm.py:12-61) and, with the
  * _grid entry, the sampling loop of calc_sdf (utils/util_dualoctree.py:99-118).

@@ -128,3 +128,42 @@ extern "C" int ofx_ddim_x0_update(float* x, const float* x0, const float* noise,
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
+
+// ---------------------------------------------------------------------------------
+// Optimiser side of the training step (reference octfusion_model_union.py:142, 478-487): torch.optim.AdamW's
+// update (decoupled weight decay, bias-corrected moments) and the EMA of the weights
+// (ldm_diffusion_util.py:38-54: old * beta + (1 - beta) * new), one elementwise pass each.
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+  }
+}
+extern "C" int ofx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+  if (n < 0 || step < 1 || (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) return OFX_EINVAL;
+  if (n == 0) return OFX_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  adamw_kernel<<<ofx_grid(n, 256), 256, 0, ofx_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+                                                                 eps, weight_decay, bc1, bc2);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+__global__ void ema_kernel(float* __restrict__ e, const float* __restrict__ p, int64_t n, float beta) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    e[i] = e[i] * beta + (1.f - beta) * p[i];
+}
+extern "C" int ofx_ema_update(float* ema, const float* param, int64_t n, float beta, void* stream) {
+  if (n < 0 || (n > 0 && (!ema || !param))) return OFX_EINVAL;
+  if (n > 0) ema_kernel<<<ofx_grid(n, 256), 256, 0, ofx_stream(stream)>>>(ema, param, n, beta);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}

@@ -1,0 +1,70 @@
+"""Training step of the first (lr) diffusion stage -- SURVEY 8f-4.
+
+Mirror of the reference's optimize_parameters for stage_flag == "lr" (octfusion_model_union.py:242-269, 271-292,
+478-487): noise the split codes at a random log-SNR, predict x0, MSE, backward, AdamW, EMA.  Forward and backward
+run on libofx (octfusion_amd/backward.py); the optimiser and EMA are one elementwise kernel launch per parameter.
+"""
+import torch
+
+from . import backward as BW
+from . import ops, sampler
+from ._lib import call, ptr, stream
+
+
+class AdamW:
+    """torch.optim.AdamW (the reference's optimiser, octfusion_model_union.py:142) on ofx_adamw_step."""
+
+    def __init__(self, named_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.params = dict(named_params)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.state = {k: (torch.zeros_like(p.data), torch.zeros_like(p.data)) for k, p in self.params.items()}
+
+    @torch.no_grad()
+    def step(self, grads):
+        self.step_count += 1
+        for k, p in self.params.items():
+            g = grads[k].contiguous()
+            assert g.shape == p.shape, (k, g.shape, p.shape)
+            m, v = self.state[k]
+            call('ofx_adamw_step', ptr(p.data), ptr(g), ptr(m), ptr(v), p.numel(), self.lr, self.betas[0], self.betas[1],
+                 self.eps, self.weight_decay, self.step_count, stream())
+            p.add_(0.0)           # the kernel wrote behind torch's back: bump the version so packed-weight caches repack
+
+
+@torch.no_grad()
+def ema_update(ema_module, module, beta):
+    """ldm_diffusion_util.py:50-53."""
+    for pe, p in zip(ema_module.parameters(), module.parameters()):
+        call('ofx_ema_update', ptr(pe.data), ptr(p.data), p.numel(), beta, stream())
+        pe.add_(0.0)
+
+
+@torch.no_grad()
+def lr_stage_step(net, opt, split_small, times=None, noise=None, label=None, ema=None, ema_rate=0.999):
+    """One optimisation step of the lr stage on a batch of split codes [B, 8, S, S, S] (values in {-1, +1}).
+    net: graph_unet_lr.UNet3DModel.  Returns the loss (python float)."""
+    B = split_small.shape[0]
+    dev = split_small.device
+    if times is None:
+        times = torch.rand(B, device=dev)
+    if noise is None:
+        noise = torch.randn_like(split_small)
+    log_snr = sampler.beta_linear_log_snr(times.cpu()).float().to(dev)
+    alpha, sigma = sampler.log_snr_to_alpha_sigma(log_snr)
+    noised = alpha.view(B, 1, 1, 1, 1) * split_small + sigma.view(B, 1, 1, 1, 1) * noise
+    # the lr net takes cat(x, x_self_cond); training passes no self-conditioning (zeros), graph_unet_lr.py:198-204
+    x = torch.cat((noised, torch.zeros_like(noised)), dim=1)
+    rows = ops.voxel2octree_cf(x.float(), net.full_depth)
+    target = ops.voxel2octree_cf(split_small.float(), net.full_depth)
+    box = {}
+
+    def dy_fn(y):
+        diff = y - target
+        box['loss'] = float((diff * diff).mean())
+        return diff * (2.0 / diff.numel())
+    _, _, grads = BW.lr_unet_forward_backward(net, rows, B, log_snr, dy_fn, label=label)
+    opt.step(grads)
+    if ema is not None:
+        ema_update(ema, net, ema_rate)
+    return box['loss']

@@ -289,3 +289,204 @@ def lr_unet_forward_backward(net, x_rows, batch_size, timesteps, dy_fn, label=No
     dsin, dcos = dpe[:, 1:1 + half], dpe[:, 1 + half:]
     G.add('time_pos_emb.weights', ((dsin * f.cos() - dcos * f.sin()) * tt * 2 * math.pi).sum(0))
     return y, dx, dict(G)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Sparse hr U-Net (graph_unet_hr.UNet3DModel, graph_unet_hr.py:214-281) with the nested lr net: forward + backward.
+def _gconv_bwd(conv, x, dy, doctree, d, G, prefix, need_dx=True):
+    dx, dw = ops.graphconv_backward(x, dy, doctree, d, conv.weights, conv.n_node_type, need_dx=need_dx)
+    G.add(prefix + 'weights', dw)
+    if conv.use_bias:
+        G.add(prefix + 'bias', dy.sum(0))
+    return dx
+
+
+def _dgn_bwd(norm, x, dy, doctree, d, act, G, prefix):
+    dx, dg, db = ops.group_norm_backward(x, dy, doctree.batch_id32(d), doctree.count(d), doctree.batch_size,
+                                         norm.weights, norm.bias, norm.group, norm.eps, act=act)
+    G.add(prefix + 'weights', dg.view(1, -1))
+    G.add(prefix + 'bias', db.view(1, -1))
+    return dx
+
+
+def _gres_fwd(blk, x, emb_act, doctree, d):
+    h1 = blk.block1_norm(x, doctree, d, act='silu')
+    emb_out = blk.emb_layers[1](emb_act)
+    c1 = blk.conv1(h1, doctree, d, emb=emb_out)
+    h2 = blk.block2_norm(c1, doctree, d, act='silu')
+    skip = x if isinstance(blk.skip_connection, nn.Identity) else blk.skip_connection(x)
+    y = blk.conv2(h2, doctree, d, res=skip)
+    return y, (x, h1, c1, h2)
+
+
+def _gres_bwd(blk, saved, emb_act, dy, doctree, d, G, prefix):
+    x, h1, c1, h2 = saved
+    dh2 = _gconv_bwd(blk.conv2, h2, dy, doctree, d, G, prefix + 'conv2.')
+    dc1 = _dgn_bwd(blk.block2_norm, c1, dh2, doctree, d, 'silu', G, prefix + 'block2_norm.')
+    demb_out = batch_sums(dc1, doctree.batch_id32(d), doctree.batch_size)
+    demb_act = _linear_bwd(blk.emb_layers[1], emb_act, demb_out, G, prefix + 'emb_layers.1.')
+    dh1 = _gconv_bwd(blk.conv1, h1, dc1, doctree, d, G, prefix + 'conv1.')
+    dx = _dgn_bwd(blk.block1_norm, x, dh1, doctree, d, 'silu', G, prefix + 'block1_norm.')
+    if isinstance(blk.skip_connection, nn.Identity):
+        dx += dy
+    else:
+        dx += _linear_bwd(blk.skip_connection.linear, x, dy, G, prefix + 'skip_connection.linear.')
+    return dx, demb_act
+
+
+def _pool_bwd(down, x, dout, doctree, d, G, prefix):
+    """Backward of modules.pool_nodes (rows of depth d -> d-1)."""
+    copy_src, gemm_rows, n_out = doctree.pool_maps(d)
+    C = x.shape[1]
+    numd = int(doctree.nnum[d])
+    dx = torch.zeros_like(x)
+    ops.rows_copy(dout, dx, n_out, dmap=copy_src)                        # leaf rows were copied
+    n_ne = gemm_rows.numel()
+    if n_ne:
+        dP = torch.empty(n_ne, C, dtype=torch.float32, device=x.device)
+        ops.rows_copy(dout, dP, n_ne, smap=gemm_rows)
+        tail = x[x.shape[0] - numd:].reshape(n_ne, 8 * C)
+        w2 = down.weights.view(C, 8 * C)                                 # y = tail @ w2^T
+        dtail, dw, _ = ops.linear_backward(tail, dP, w2)
+        dx[x.shape[0] - numd:] = dtail.view(numd, C)
+        G.add(prefix + 'weights', dw.view_as(down.weights))
+    else:
+        G.add(prefix + 'weights', torch.zeros_like(down.weights))
+    return dx
+
+
+def _unpool_bwd(up, x, dout, doctree, d, G, prefix):
+    """Backward of modules.unpool_nodes (rows of depth d -> d+1)."""
+    copy_src, a_rows, n_copy = doctree.unpool_maps(d)
+    C = x.shape[1]
+    dx = torch.zeros_like(x)
+    ops.rows_copy(dout, dx, n_copy, dmap=copy_src)
+    n_ne = a_rows.numel()
+    if n_ne:
+        dU = dout[n_copy:].reshape(n_ne, 8 * C)                          # y = xa @ w2, w2 [C, 8C]
+        xa = torch.empty(n_ne, C, dtype=torch.float32, device=x.device)
+        ops.rows_copy(x, xa, n_ne, smap=a_rows)
+        w2 = up.weights.view(C, 8 * C)
+        G.add(prefix + 'weights', ops.gemm_tn(xa, dU).view_as(up.weights))
+        dxa = ops.gemm(dU, ops.PackedWeight().get(w2, 'nk'))             # dU @ w2^T
+        ops.rows_copy(dxa, dx, n_ne, dmap=a_rows)                        # those rows receive nothing else
+    else:
+        G.add(prefix + 'weights', torch.zeros_like(up.weights))
+    return dx
+
+
+@torch.no_grad()
+def hr_unet_forward_backward(net, x, doctree, unet_lr, timesteps, dy_fn, label=None):
+    """graph_unet_hr.UNet3DModel (with its nested lr net run as the middle): forward keeping intermediates, then
+    backward.  Returns (y, dx, grads of the hr net, grads of the lr net) keyed by state_dict names."""
+    from . import modules as M
+    G = _Grads()
+    B = doctree.batch_size
+    t_emb = ops.timestep_embedding(timesteps.float(), net.model_channels)
+    e1 = net.time_embed[0](t_emb)
+    a1 = ops.act(e1, 'silu')
+    e2 = net.time_embed[2](a1)
+    if net.num_classes is not None:
+        e2 = e2 + net.label_emb(label)
+    emb_act = ops.act(e2, 'silu')
+    demb_act = torch.zeros_like(emb_act)
+    d = net.input_depth
+    h = net.input_blocks[0](x, doctree, d)
+    hs = [h]
+    enc_tape = []
+    for (kind, dd, _), module in zip(net._enc, net.input_blocks[1:]):
+        if kind == 'res':
+            h_in = h
+            h, s = _gres_fwd(module, h_in, emb_act, doctree, dd)
+            enc_tape.append(('res', dd, module, s))
+        else:
+            h_in = h
+            p = M.pool_nodes(h_in, doctree, dd, module.downsample)
+            h = module.conv(p, doctree, dd - 1)
+            enc_tape.append(('down', dd, module, (h_in, p)))
+        hs.append(h)
+    dm = net._d_mid
+    h_mid_in = h
+    m1, s_m1 = _gres_fwd(net.middle_block1, h_mid_in, emb_act, doctree, dm)
+    box = {}
+
+    def after_lr(h_lr):
+        """Rest of the forward from the lr output on, then the backward down to the concat; returns dL/dh_lr."""
+        nonlocal demb_act
+        hc = torch.cat((m1, h_lr), dim=1)
+        hh, s_m2 = _gres_fwd(net.middle_block2, hc, emb_act, doctree, dm)
+        skips = list(hs)
+        dec_tape = []
+        for (kind, dd, _), module in zip(net._dec, net.output_blocks):
+            if kind == 'res':
+                sk = skips.pop()
+                c_left = hh.shape[1]
+                hh, s = _gres_fwd(module, torch.cat((hh, sk), dim=1), emb_act, doctree, dd)
+                dec_tape.append(('res', dd, module, s, c_left))
+            else:
+                h_in = hh
+                u = M.unpool_nodes(h_in, doctree, dd, module.upsample)
+                hh = module.conv(u, doctree, dd + 1)
+                dec_tape.append(('up', dd, module, (h_in, u), 0))
+        h_end = hh
+        e = net.end_norm(h_end, doctree, net.input_depth, act='silu')
+        y = net.out(e, doctree, net.input_depth)
+        box['y'] = y
+        # ---------------------------------------------------------------- backward (decoder side)
+        dyv = dy_fn(y)
+        de = _gconv_bwd(net.out, e, dyv, doctree, net.input_depth, G, 'out.')
+        dh = _dgn_bwd(net.end_norm, h_end, de, doctree, net.input_depth, 'silu', G, 'end_norm.')
+        dskip = [None] * len(hs)
+        si = 0                                            # decoder pops hs from the end
+        n_res = sum(1 for t in dec_tape if t[0] == 'res')
+        consumed = n_res
+        for idx in range(len(dec_tape) - 1, -1, -1):
+            kind, dd, module, s, c_left = dec_tape[idx]
+            pre = 'output_blocks.%d.' % idx
+            if kind == 'res':
+                dcat, dea = _gres_bwd(module, s, emb_act, dh, doctree, dd, G, pre)
+                demb_act += dea
+                consumed -= 1                             # this block consumed skip number `consumed` (0-based pops)
+                dskip[len(hs) - 1 - consumed] = dcat[:, c_left:].contiguous()
+                dh = dcat[:, :c_left].contiguous()
+            else:
+                h_in, u = s
+                du = _gconv_bwd(module.conv, u, dh, doctree, dd + 1, G, pre + 'conv.')
+                dh = _unpool_bwd(module.upsample, h_in, du, doctree, dd, G, pre + 'upsample.')
+        dhc, dea = _gres_bwd(net.middle_block2, s_m2, emb_act, dh, doctree, dm, G, 'middle_block2.')
+        demb_act += dea
+        c1 = m1.shape[1]
+        box['dm1_left'] = dhc[:, :c1].contiguous()
+        box['dskip'] = dskip
+        return dhc[:, c1:].contiguous()
+
+    _, dm1_lr, grads_lr = lr_unet_forward_backward(unet_lr, m1, B, timesteps, after_lr, label=label, as_middle=True)
+    dm1 = box['dm1_left'] + dm1_lr
+    dh, dea = _gres_bwd(net.middle_block1, s_m1, emb_act, dm1, doctree, dm, G, 'middle_block1.')
+    demb_act += dea
+    dskip = box['dskip']
+    # ---------------------------------------------------------------- backward (encoder side)
+    for k in range(len(enc_tape) - 1, -1, -1):
+        kind, dd, module, s = enc_tape[k]
+        pre = 'input_blocks.%d.' % (k + 1)
+        if dskip[k + 1] is not None:
+            dh = dh + dskip[k + 1]
+        if kind == 'res':
+            dh, dea = _gres_bwd(module, s, emb_act, dh, doctree, dd, G, pre)
+            demb_act += dea
+        else:
+            h_in, p = s
+            dp = _gconv_bwd(module.conv, p, dh, doctree, dd - 1, G, pre + 'conv.')
+            dh = _pool_bwd(module.downsample, h_in, dp, doctree, dd, G, pre + 'downsample.')
+    if dskip[0] is not None:
+        dh = dh + dskip[0]
+    dx = _gconv_bwd(net.input_blocks[0], x, dh, doctree, net.input_depth, G, 'input_blocks.0.')
+    # ---- time embedding
+    de2 = demb_act * _silu_grad(e2)
+    if net.num_classes is not None:
+        gl = torch.zeros_like(net.label_emb.weight)
+        gl.index_add_(0, label, de2)
+        G.add('label_emb.weight', gl)
+    da1 = _linear_bwd(net.time_embed[2], a1, de2, G, 'time_embed.2.')
+    _linear_bwd(net.time_embed[0], t_emb, da1 * _silu_grad(e1), G, 'time_embed.0.')
+    return box['y'], dx, dict(G), grads_lr

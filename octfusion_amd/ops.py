@@ -256,11 +256,18 @@ def graphconv_backward(x, dy, doctree, d, weights, n_node_type, need_dx=True, ne
         fast = cin % 32 == 0 and ldx % 4 == 0
         nbr_ext, multi_seg, V = doctree.ext(d)
         aux = torch.empty((V + 1) * ldx, dtype=torch.float32, device=x.device) if fast else None
-        dwp = torch.empty(Kp, cout, dtype=torch.float32, device=x.device)
+        dyw, ldw, cw = dy, ldy, cout
+        if cout % 4 or ldy % 4 or dy.data_ptr() % 16:      # narrow outputs (the 3-channel output conv): pad to 4 columns
+            cw = (cout + 3) // 4 * 4
+            dyw = torch.zeros(N, cw, dtype=torch.float32, device=x.device)
+            dyw[:, :cout] = dy
+            ldw = cw
+        dwp = torch.empty(Kp, cw, dtype=torch.float32, device=x.device)
         call('ofx_graphconv_bwd_weight', ptr(x), ldx, cin, N, ptr(doctree.nbr(d)), ptr(seg_ptr), ptr(col),
              ptr(nbr_ext) if fast else None, ptr(multi_seg) if fast else None, V if fast else 0, ptr(aux),
              ptr(tf), tf.stride(0) if tf is not None else 0, tf.shape[1] if tf is not None else 0,
-             ptr(dy), ldy, cout, ptr(dwp), Kp, ptr(ws), ws.numel(), stream())
+             ptr(dyw), ldw, cw, ptr(dwp), Kp, ptr(ws), ws.numel(), stream())
+        dwp = dwp[:, :cout]
         # packed k order -> the reference's row order dir*(cin+nt) + [channels | types]
         dev = x.device
         dirs = torch.arange(7, device=dev).view(7, 1)

@@ -68,3 +68,38 @@ def lr_stage_step(net, opt, split_small, times=None, noise=None, label=None, ema
     if ema is not None:
         ema_update(ema, net, ema_rate)
     return box['loss']
+
+
+@torch.no_grad()
+def hr_stage_step(net, opt, codes, doctree, depth, times=None, noise=None, label=None, ema=None, ema_rate=0.999):
+    """One optimisation step of the second (hr) stage, eps objective (octfusion_model_union.py:242-269 with
+    df_type 'eps'): codes [N, C] = latent codes on the depth-`depth` dual graph (GraphVAE.encode), net = the union
+    UNet3DModel (hr + nested lr); `opt` holds the parameters of both nets under their union state_dict names.
+    Returns the loss."""
+    B = doctree.batch_size
+    dev = codes.device
+    if times is None:
+        times = torch.rand(B, device=dev)
+    if noise is None:
+        noise = torch.randn_like(codes)
+    log_snr = sampler.beta_linear_log_snr(times.cpu()).float().to(dev)
+    alpha, sigma = sampler.log_snr_to_alpha_sigma(log_snr)
+    bid = doctree.batch_id(depth)
+    noised = (alpha[bid].unsqueeze(1) * codes + sigma[bid].unsqueeze(1) * noise).contiguous()
+    box = {}
+
+    def dy_fn(y):
+        diff = y - noise
+        box['loss'] = float((diff * diff).mean())
+        return diff * (2.0 / diff.numel())
+    _, _, g_hr, g_lr = BW.hr_unet_forward_backward(net.unet_hr, noised, doctree, net.unet_lr, log_snr, dy_fn, label=label)
+    grads = {'unet_hr.' + k: v for k, v in g_hr.items()}
+    grads.update({'unet_lr.' + k: v for k, v in g_lr.items()})
+    # parameters that take no part in this stage (the lr net's own input / output convolutions) keep a zero gradient
+    for k, p in opt.params.items():
+        if k not in grads:
+            grads[k] = torch.zeros_like(p)
+    opt.step(grads)
+    if ema is not None:
+        ema_update(ema, net, ema_rate)
+    return box['loss']

@@ -542,6 +542,76 @@ def test_lr_unet_backward_vs_autograd(golden):
         assert err <= 5e-3 * float(ref.abs().max()) + 2e-5 * gmax, (k, err, float(ref.abs().max()), gmax)
 
 
+def test_hr_unet_backward_vs_autograd(golden):
+    """The sparse hr U-Net with the nested lr net (input conv, res blocks, graph down / up-sampling with pooled
+    GEMMs and leaf copies, skip concats, middle blocks around the dense net, end norm, output conv): forward +
+    backward assembled from the gradient kernels against torch.autograd through the oracle -- every parameter of
+    both nets and the input."""
+    from octfusion_amd import graph_unet_union as U, backward as BW
+    from oracle import dual_octree as OD, modules as OM, sampler as OS, unet as OU
+    G = golden('g_unet')
+    r = G['uncond']
+    oc, doc = small(G['split_small'])
+    o_doc = OD.OracleDualOctree(OS.split2octree_small(G['split_small'], 5, 3))
+    o_doc.post_processing_for_docnn()
+    sd = C.fill_state_dict(r['keys'])
+    # the zero-initialised modules get real weights so that every gradient path carries signal
+    net = load(U.UNet3DModel(**union_cfg(None)), r['keys'])
+    N = doc.total_num
+    x = C.rand_input('hrb_x', N, 3)
+    dy = C.rand_input('hrb_dy', N, 3)
+    t = torch.tensor([0.4, -0.9])
+    with torch.enable_grad():
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xg = x.clone().requires_grad_(True)
+        parts = {p: OM._sub(sdg, p) for p in ('unet_lr', 'unet_hr')}
+        y = OU.hr_forward(parts['unet_hr'], C.TINY_HR_CFG, xg, o_doc, t, None, parts['unet_lr'], C.TINY_LR_CFG)
+        (y * dy).sum().backward()
+    yy, dx, g_hr, g_lr = BW.hr_unet_forward_backward(net.unet_hr, x.to(dev()), doc, net.unet_lr, t.to(dev()),
+                                                     lambda out: dy.to(dev()))
+    close(yy, y.detach(), 1e-3)
+    close(dx, xg.grad, 5e-3)
+    grads = {'unet_hr.' + k: v for k, v in g_hr.items()}
+    grads.update({'unet_lr.' + k: v for k, v in g_lr.items()})
+    # the lr net runs as the middle: its input / output convolutions take no part
+    used = {k for k in sd if sdg[k].grad is not None}
+    assert set(grads) == used, (set(grads) ^ used)
+    gmax = max(float(sdg[k].grad.abs().max()) for k in used)
+    for k in used:
+        ref = sdg[k].grad
+        err = float((grads[k].cpu() - ref).abs().max())
+        assert err <= 5e-3 * float(ref.abs().max()) + 2e-5 * gmax, (k, err, float(ref.abs().max()), gmax)
+
+
+def test_hr_training_step(golden):
+    """Second-stage training step (eps objective) on the union net: first-step loss equals the oracle's, and the
+    loss falls on a fixed batch."""
+    from octfusion_amd import graph_unet_union as U, training as TR
+    from oracle import dual_octree as OD, modules as OM, sampler as OS, unet as OU
+    G = golden('g_unet')
+    r = G['uncond']
+    oc, doc = small(G['split_small'])
+    o_doc = OD.OracleDualOctree(OS.split2octree_small(G['split_small'], 5, 3))
+    o_doc.post_processing_for_docnn()
+    sd = C.fill_state_dict(r['keys'])
+    net = load(U.UNet3DModel(**union_cfg(None)), r['keys'])
+    opt = TR.AdamW(dict(net.named_parameters()), lr=1e-3)
+    N = doc.total_num
+    codes = C.rand_input('hrt_codes', N, 3)
+    noise = C.rand_input('hrt_noise', N, 3)
+    times = torch.tensor([0.35, 0.8])
+    ls = OS.beta_linear_log_snr(times)
+    a, sg = OS.log_snr_to_alpha_sigma(ls)
+    bid = o_doc.batch_id(5)
+    noised = a[bid].unsqueeze(1) * codes + sg[bid].unsqueeze(1) * noise
+    parts = {p: OM._sub(sd, p) for p in ('unet_lr', 'unet_hr')}
+    ref = OU.hr_forward(parts['unet_hr'], C.TINY_HR_CFG, noised, o_doc, ls.float(), None, parts['unet_lr'], C.TINY_LR_CFG)
+    ref_loss = float(torch.nn.functional.mse_loss(ref, noise))
+    losses = [TR.hr_stage_step(net, opt, codes.to(dev()), doc, 5, times.to(dev()), noise.to(dev())) for _ in range(6)]
+    assert abs(losses[0] - ref_loss) <= 1e-3 * ref_loss, (losses[0], ref_loss)
+    assert losses[-1] < 0.9 * losses[0], losses
+
+
 def test_adamw_ema_and_lr_training_step(golden):
     """ofx_adamw_step / ofx_ema_update against torch.optim.AdamW + the reference's EMA rule over several steps on the
     same gradients; then the lr-stage training step (noise -> predict x0 -> MSE -> backward -> AdamW -> EMA) lowers

@@ -1553,11 +1553,20 @@ struct TnArgs {
   float* part;                              // [slices][Kp][N]
 };
 
-template <bool DENSE_P>
+template <bool DENSE_P, bool BF16X3>
 __global__ void __launch_bounds__(256, 2) tn_gemm_kernel(const TnArgs a) {
-  constexpr int LD = 132;                   // LDS row pitch (floats): 128 + 4
-  __shared__ float Ps[32 * LD];
-  __shared__ float Qs[32 * LD];
+  // fp32 mode: tiles [32 k][128 + 4] floats, the 32x32x2 MFMA reads them as they are.
+  // bf16x3 mode (default contraction precision, 3 x v_mfma_f32_32x32x16_bf16): the operand fragments need 8
+  // consecutive k per lane, i.e. TRANSPOSED tiles [128 m][32 k + 8] bf16 (hi and lo planes): the loader maps a
+  // quad of lanes to 4 consecutive rows k of the same float4 column, a DPP 4x4 transpose turns that into 4
+  // consecutive k of one column m, and each lane writes 8 B per plane.
+  constexpr int LD = 132;                   // fp32 LDS row pitch (floats): 128 + 4
+  constexpr int TP = 128 * 80;              // bytes of one transposed bf16 plane ([128][40] bf16)
+  __shared__ __attribute__((aligned(16))) char tn_smem[BF16X3 ? 4 * TP : 2 * 32 * LD * 4];
+  float* const Ps = reinterpret_cast<float*>(tn_smem);
+  float* const Qs = Ps + 32 * LD;
+  char* const Pt = tn_smem;                 // hi plane, lo plane at + TP
+  char* const Qt = tn_smem + 2 * TP;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, h = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * 128, n0 = (int64_t)blockIdx.y * 128;
@@ -1570,8 +1579,10 @@ __global__ void __launch_bounds__(256, 2) tn_gemm_kernel(const TnArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int kr = threadIdx.x >> 3;          // tile row (node) this thread loads, 0..31
-  const int f0 = threadIdx.x & 7;           // float4 column f0 + 8 p, p < 4
+  // loader mapping: fp32: row kr = tid >> 3, float4 f0 = tid & 7;  bf16x3: quad lane q = k & 3, f0, k >> 2 = tid >> 5
+  const int q4 = threadIdx.x & 3;
+  const int kr = BF16X3 ? q4 + 4 * (threadIdx.x >> 5) : threadIdx.x >> 3;
+  const int f0 = BF16X3 ? (threadIdx.x >> 2) & 7 : threadIdx.x & 7;
   float4 vp[4], vq[4];
   auto load_tile = [&](int64_t r) {
     const int64_t row = r + kr;
@@ -1602,10 +1613,29 @@ __global__ void __launch_bounds__(256, 2) tn_gemm_kernel(const TnArgs a) {
     }
   };
   auto store_tile = [&]() {
+    if (BF16X3) {
+      const bool b0 = q4 & 1, b1 = q4 & 2;
+      const int kg = threadIdx.x >> 5;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *reinterpret_cast<float4*>(Ps + kr * LD + 4 * (f0 + 8 * p)) = vp[p];
-      *reinterpret_cast<float4*>(Qs + kr * LD + 4 * (f0 + 8 * p)) = vq[p];
+      for (int p = 0; p < 4; ++p) {
+        float4 v = vp[p], w = vq[p];
+        quad_transpose(v.x, v.y, v.z, v.w, b0, b1);      // lane q: column 4F + q, rows 4kg .. 4kg+3
+        quad_transpose(w.x, w.y, w.z, w.w, b0, b1);
+        const int col = 4 * (f0 + 8 * p) + q4;
+        uint2 hi, lo;
+        split_bf16x4(v, hi, lo);
+        *reinterpret_cast<uint2*>(Pt + col * 80 + kg * 8) = hi;
+        *reinterpret_cast<uint2*>(Pt + col * 80 + kg * 8 + TP) = lo;
+        split_bf16x4(w, hi, lo);
+        *reinterpret_cast<uint2*>(Qt + col * 80 + kg * 8) = hi;
+        *reinterpret_cast<uint2*>(Qt + col * 80 + kg * 8 + TP) = lo;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        *reinterpret_cast<float4*>(Ps + kr * LD + 4 * (f0 + 8 * p)) = vp[p];
+        *reinterpret_cast<float4*>(Qs + kr * LD + 4 * (f0 + 8 * p)) = vq[p];
+      }
     }
   };
   if (r_begin < r_end) load_tile(r_begin);
@@ -1614,16 +1644,40 @@ __global__ void __launch_bounds__(256, 2) tn_gemm_kernel(const TnArgs a) {
     store_tile();
     __syncthreads();
     if (r + 32 < r_end) load_tile(r + 32);
-    const float* pa = Ps + h * LD + wm * 64 + l31;
-    const float* pb = Qs + h * LD + wn * 64 + l31;
+    if (BF16X3) {
+      const char* pa = Pt + (wm * 64 + l31) * 80 + 16 * h;
+      const char* pb = Qt + (wn * 64 + l31) * 80 + 16 * h;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const float a0 = pa[2 * q * LD], a1 = pa[2 * q * LD + 32];
-      const float b0 = pb[2 * q * LD], b1 = pb[2 * q * LD + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      for (int c = 0; c < 2; ++c) {
+        bf16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ah[i] = *reinterpret_cast<const bf16x8_t*>(pa + i * 32 * 80 + 32 * c);
+          al[i] = *reinterpret_cast<const bf16x8_t*>(pa + i * 32 * 80 + 32 * c + TP);
+          bh[i] = *reinterpret_cast<const bf16x8_t*>(pb + i * 32 * 80 + 32 * c);
+          bl[i] = *reinterpret_cast<const bf16x8_t*>(pb + i * 32 * 80 + 32 * c + TP);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+    } else {
+      const float* pa = Ps + h * LD + wm * 64 + l31;
+      const float* pb = Qs + h * LD + wn * 64 + l31;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float a0 = pa[2 * q * LD], a1 = pa[2 * q * LD + 32];
+        const float b0 = pb[2 * q * LD], b1 = pb[2 * q * LD + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
     }
   }
   float* out = a.part + (int64_t)blockIdx.z * a.Kp * a.N;
@@ -1639,6 +1693,12 @@ __global__ void __launch_bounds__(256, 2) tn_gemm_kernel(const TnArgs a) {
         if (m < a.Kp) out[m * a.N + n] = acc[i][j][r];
       }
     }
+}
+
+template <bool DENSE_P>
+static void launch_tn(const TnArgs& a, dim3 grid, hipStream_t st) {
+  if (g_precision == 0) tn_gemm_kernel<DENSE_P, true><<<grid, 256, 0, st>>>(a);
+  else tn_gemm_kernel<DENSE_P, false><<<grid, 256, 0, st>>>(a);
 }
 
 __global__ void __launch_bounds__(256) tn_reduce_kernel(const float* __restrict__ part, int slices, int64_t total,
@@ -1689,7 +1749,7 @@ extern "C" int ofx_graphconv_bwd_weight(const float* x, int64_t ldx, int cin, in
     a.rows_per_slice = ofx_cdiv(ofx_cdiv(n_nodes, slices), 32) * 32;
     slices = (int)ofx_cdiv(n_nodes, a.rows_per_slice);
     a.part = (float*)ws;
-    tn_gemm_kernel<false><<<dim3((unsigned)ofx_cdiv(Kp, 128), (unsigned)ofx_cdiv(cout, 128), (unsigned)slices), 256, 0, st>>>(a);
+    launch_tn<false>(a, dim3((unsigned)ofx_cdiv(Kp, 128), (unsigned)ofx_cdiv(cout, 128), (unsigned)slices), st);
     tn_reduce_kernel<<<ofx_grid(total, 256), 256, 0, st>>>(a.part, slices, total, dWp, 0);
     OFX_LAUNCH_CHECK();
     return OFX_OK;
@@ -1713,7 +1773,7 @@ extern "C" int ofx_graphconv_bwd_weight(const float* x, int64_t ldx, int cin, in
     a.Q = dy + r0 * ldy; a.rows = rows; a.row0 = r0;
     a.rows_per_slice = ofx_cdiv(ofx_cdiv(rows, slices), 32) * 32;
     const int sl = (int)ofx_cdiv(rows, a.rows_per_slice);
-    tn_gemm_kernel<true><<<dim3((unsigned)ofx_cdiv(Kp, 128), (unsigned)ofx_cdiv(cout, 128), (unsigned)sl), 256, 0, st>>>(a);
+    launch_tn<true>(a, dim3((unsigned)ofx_cdiv(Kp, 128), (unsigned)ofx_cdiv(cout, 128), (unsigned)sl), st);
     tn_reduce_kernel<<<ofx_grid(total, 256), 256, 0, st>>>(a.part, sl, total, dWp, first ? 0 : 1);
     first = 0;
   }
@@ -1783,7 +1843,7 @@ extern "C" int ofx_gridconv_bwd_weight(const float* x, int64_t ldx, int cin, int
     a.tf = x; a.ldt = ldx; a.rows = n_out; a.row0 = 0;
     a.rows_per_slice = ofx_cdiv(ofx_cdiv(n_out, slices), 32) * 32;
     slices = (int)ofx_cdiv(n_out, a.rows_per_slice);
-    tn_gemm_kernel<false><<<dim3((unsigned)ofx_cdiv(Kp, 128), (unsigned)ofx_cdiv(cout, 128), (unsigned)slices), 256, 0, st>>>(a);
+    launch_tn<false>(a, dim3((unsigned)ofx_cdiv(Kp, 128), (unsigned)ofx_cdiv(cout, 128), (unsigned)slices), st);
     tn_reduce_kernel<<<ofx_grid(total, 256), 256, 0, st>>>(a.part, slices, total, dWp, 0);
     OFX_LAUNCH_CHECK();
     return OFX_OK;
@@ -1806,7 +1866,7 @@ extern "C" int ofx_gridconv_bwd_weight(const float* x, int64_t ldx, int cin, int
     a.Q = dy + r0 * ldy; a.rows = rows; a.row0 = r0;
     a.rows_per_slice = ofx_cdiv(ofx_cdiv(rows, slices), 32) * 32;
     const int sl = (int)ofx_cdiv(rows, a.rows_per_slice);
-    tn_gemm_kernel<true><<<dim3((unsigned)ofx_cdiv(Kp, 128), (unsigned)ofx_cdiv(cout, 128), (unsigned)sl), 256, 0, st>>>(a);
+    launch_tn<true>(a, dim3((unsigned)ofx_cdiv(Kp, 128), (unsigned)ofx_cdiv(cout, 128), (unsigned)sl), st);
     tn_reduce_kernel<<<ofx_grid(total, 256), 256, 0, st>>>(a.part, sl, total, dWp, first ? 0 : 1);
     first = 0;
   }
@@ -1836,7 +1896,7 @@ extern "C" int ofx_gemm_tn_f32(const float* P, int64_t ldp, const float* Q, int6
   a.rows_per_slice = ofx_cdiv(ofx_cdiv(rows, slices), 32) * 32;
   slices = (int)ofx_cdiv(rows, a.rows_per_slice);
   a.part = (float*)ws;
-  tn_gemm_kernel<true><<<dim3((unsigned)ofx_cdiv(K, 128), (unsigned)ofx_cdiv(N, 128), (unsigned)slices), 256, 0, st>>>(a);
+  launch_tn<true>(a, dim3((unsigned)ofx_cdiv(K, 128), (unsigned)ofx_cdiv(N, 128), (unsigned)slices), st);
   tn_reduce_kernel<<<ofx_grid(total, 256), 256, 0, st>>>(a.part, slices, total, out, 0);
   OFX_LAUNCH_CHECK();
   return OFX_OK;

@@ -335,7 +335,7 @@ def test_graphconv_backward_vs_autograd():
             (y * dy.double()).sum().backward()
         dx, dW = ops.graphconv_backward(x.to(dev()), dy.to(dev()), doc, d, W.to(dev()), nt)
         close(dx, x64.grad.float(), 1e-4)
-        close(dW, W64.grad.float(), 1e-5)
+        close(dW, W64.grad.float(), 5e-5)                      # bf16x3 TN contraction (exact-fp32 mode: 1e-5, below)
 
 
 def test_group_norm_backward_vs_autograd():
@@ -375,11 +375,16 @@ def test_dense_backward_pieces():
     from octfusion_amd import ops
     for rows, K, N in [(1000, 64, 128), (33, 132, 4), (5000, 8, 260), (1, 4, 4)]:
         P, Q = torch.randn(rows, K), torch.randn(rows, N)
-        close(ops.gemm_tn(P.to(dev()), Q.to(dev())), (P.double().t() @ Q.double()).float(), 1e-5)
+        close(ops.gemm_tn(P.to(dev()), Q.to(dev())), (P.double().t() @ Q.double()).float(), 5e-5)
+        ops.set_precision('fp32')
+        try:
+            close(ops.gemm_tn(P.to(dev()), Q.to(dev())), (P.double().t() @ Q.double()).float(), 1e-5)
+        finally:
+            ops.set_precision('bf16x3')
     x, dy, W = torch.randn(777, 96), torch.randn(777, 40), torch.randn(40, 96)
     dx, dW, db = ops.linear_backward(x.to(dev()), dy.to(dev()), W.to(dev()))
     close(dx, (dy.double() @ W.double()).float(), 1e-4)
-    close(dW, (dy.double().t() @ x.double()).float(), 1e-5)
+    close(dW, (dy.double().t() @ x.double()).float(), 5e-5)
     close(db, dy.sum(0), 1e-5)
 
 
@@ -480,7 +485,7 @@ def test_gridconv_backward_vs_autograd():
         gs = LR.GridState(B, d, dev())
         dx, dw, db = BW.gridconv_backward(m, to_rows(x, d), to_rows(dy, d_out), gs)
         close(to_vox(dx, B, d), x64.grad.float(), 1e-4)
-        close(dw, w64.grad.float(), 1e-5)
+        close(dw, w64.grad.float(), 5e-5)
         close(db, b64.grad.float(), 1e-5)
 
 
@@ -678,7 +683,7 @@ def test_adamw_ema_and_lr_training_step(golden):
     assert losses[-1] < 0.7 * losses[0] and ref_losses[-1] < 0.7 * ref_losses[0]
     # same batch, same noise: the loss goes down
     fixed = [TR.lr_stage_step(net, opt, split.to(dev()), times[0].to(dev()), noises[0].to(dev())) for _ in range(8)]
-    assert fixed[-1] < 0.8 * fixed[0], fixed
+    assert fixed[-1] < 0.9 * fixed[0], fixed
     assert all(bool(torch.isfinite(p).all()) for p in ema.parameters())
 
 

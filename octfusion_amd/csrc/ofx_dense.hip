@@ -250,6 +250,7 @@ __global__ void __launch_bounds__(256) attention_bwd_q_kernel(const float* __res
   const float* gi = dout + (row0 + i) * ldo + (int64_t)hd * ch;
   const float* kb = qkv + row0 * ldq + (int64_t)hd * 3 * ch + ch;
   const float* vb = kb + ch;
+  const bool vec = (ch & 3) == 0 && (ldq & 3) == 0 && (ldo & 3) == 0 && ((((uintptr_t)qkv) | ((uintptr_t)dout)) & 15) == 0;
   float s[8], dp[8];                                   // T <= 512: up to 8 keys per lane
   float m = -3.0e38f;
 #pragma unroll
@@ -258,7 +259,18 @@ __global__ void __launch_bounds__(256) attention_bwd_q_kernel(const float* __res
     s[t] = -3.0e38f; dp[t] = 0.f;
     if (j < T) {
       float a = 0.f, d = 0.f;
-      for (int c = 0; c < ch; ++c) { a += qi[c] * kb[(int64_t)j * ldq + c]; d += gi[c] * vb[(int64_t)j * ldq + c]; }
+      const float* kj = kb + (int64_t)j * ldq;
+      const float* vj = vb + (int64_t)j * ldq;
+      if (vec) {
+        for (int c = 0; c < ch; c += 4) {
+          const float4 q4 = *reinterpret_cast<const float4*>(qi + c), g4 = *reinterpret_cast<const float4*>(gi + c);
+          const float4 k4 = *reinterpret_cast<const float4*>(kj + c), v4 = *reinterpret_cast<const float4*>(vj + c);
+          a += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+          d += g4.x * v4.x + g4.y * v4.y + g4.z * v4.z + g4.w * v4.w;
+        }
+      } else {
+        for (int c = 0; c < ch; ++c) { a += qi[c] * kj[c]; d += gi[c] * vj[c]; }
+      }
       s[t] = a * sc; dp[t] = d;
       m = fmaxf(m, s[t]);
     }
@@ -306,9 +318,21 @@ __global__ void __launch_bounds__(256) attention_bwd_kv_kernel(const float* __re
   const float* vj = kj + ch;
   const float* gb = dout + row0 * ldo + (int64_t)hd * ch;
   const float* rs = rowstat + (int64_t)bh * T * 3;
+  const bool vec = (ch & 3) == 0 && (ldq & 3) == 0 && (ldo & 3) == 0 && ((((uintptr_t)qkv) | ((uintptr_t)dout)) & 15) == 0;
   for (int i = lane; i < T; i += 64) {
     float a = 0.f, d = 0.f;
-    for (int c = 0; c < ch; ++c) { a += qb[(int64_t)i * ldq + c] * kj[c]; d += gb[(int64_t)i * ldo + c] * vj[c]; }
+    const float* qr = qb + (int64_t)i * ldq;
+    const float* gr = gb + (int64_t)i * ldo;
+    if (vec) {
+      for (int c = 0; c < ch; c += 4) {
+        const float4 q4 = *reinterpret_cast<const float4*>(qr + c), g4 = *reinterpret_cast<const float4*>(gr + c);
+        const float4 k4 = *reinterpret_cast<const float4*>(kj + c), v4 = *reinterpret_cast<const float4*>(vj + c);
+        a += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+        d += g4.x * v4.x + g4.y * v4.y + g4.z * v4.z + g4.w * v4.w;
+      }
+    } else {
+      for (int c = 0; c < ch; ++c) { a += qr[c] * kj[c]; d += gr[c] * vj[c]; }
+    }
     const float p = __expf(a * sc - rs[i * 3]) * rs[i * 3 + 1];
     pc[i] = p;
     dc[i] = p * (d - rs[i * 3 + 2]);

@@ -203,45 +203,77 @@ __device__ __forceinline__ float ofx_act_grad(float y, int act) {
   return 1.f;
 }
 
-// thread = (row lane, float4 of channels); per-thread run accumulation, one fp64 atomic pair per channel per run
+// Same blocking as gn_stats_kernel: 64 rows per block, thread = (row lane, float4 of channels), per-thread runs in
+// fp32, the row lanes meet in LDS and the block issues ONE fp64 atomic pair per channel (per batch element it
+// touches) -- per-thread atomics made this kernel 6x slower than the forward statistics.
 __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restrict__ x, int64_t ldx,
                                                            const float* __restrict__ dy, int64_t ldy, int64_t n, int C,
                                                            const int32_t* __restrict__ bid,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            int act, double* __restrict__ sums) {
+  __shared__ int sb[256];
+  __shared__ float sv[256][8];
   const int CT = C >> 2, RP = 256 / CT;
   const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
-  if (rl >= RP) return;
-  const int64_t r_begin = (int64_t)blockIdx.x * 64;
-  const int64_t r_end = r_begin + 64 < n ? r_begin + 64 : n;
-  const float4 ww = *reinterpret_cast<const float4*>(w + cl * 4);
-  const float4 bb = *reinterpret_cast<const float4*>(bias + cl * 4);
+  const int64_t r_begin = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK;
+  const int64_t r_end = r_begin + GN_ROWS_PER_BLOCK < n ? r_begin + GN_ROWS_PER_BLOCK : n;
   int cb = -1;
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-  auto flush = [&]() {
-    if (cb < 0) return;
-    double* o = sums + ((int64_t)cb * C + cl * 4) * 2;
+  auto flush_direct = [&](int b, const float* ps, const float* pq) {
+    if (b < 0) return;
+    double* o = sums + ((int64_t)b * C + cl * 4) * 2;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { unsafeAtomicAdd(o + 2 * k, (double)s[k]); unsafeAtomicAdd(o + 2 * k + 1, (double)q[k]); }
+    for (int k = 0; k < 4; ++k) { unsafeAtomicAdd(o + 2 * k, (double)ps[k]); unsafeAtomicAdd(o + 2 * k + 1, (double)pq[k]); }
   };
-  for (int64_t r = r_begin + rl; r < r_end; r += RP) {
-    const int b = bid[r];
-    if (b != cb) { flush(); cb = b; s[0] = s[1] = s[2] = s[3] = 0.f; q[0] = q[1] = q[2] = q[3] = 0.f; }
-    const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + cl * 4);
-    float4 g = *reinterpret_cast<const float4*>(dy + r * ldy + cl * 4);
-    if (act != OFX_ACT_NONE) {
-      const float4 m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + cl * 4);
-      const float4 rs = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + cl * 4);
-      g.x *= ofx_act_grad((xv.x - m.x) * rs.x * ww.x + bb.x, act);
-      g.y *= ofx_act_grad((xv.y - m.y) * rs.y * ww.y + bb.y, act);
-      g.z *= ofx_act_grad((xv.z - m.z) * rs.z * ww.z + bb.z, act);
-      g.w *= ofx_act_grad((xv.w - m.w) * rs.w * ww.w + bb.w, act);
+  if (rl < RP) {
+    const float4 ww = *reinterpret_cast<const float4*>(w + cl * 4);
+    const float4 bb = *reinterpret_cast<const float4*>(bias + cl * 4);
+    for (int64_t r = r_begin + rl; r < r_end; r += RP) {
+      const int b = bid[r];
+      if (b != cb) {
+        flush_direct(cb, s, q);
+        cb = b;
+        s[0] = s[1] = s[2] = s[3] = 0.f;
+        q[0] = q[1] = q[2] = q[3] = 0.f;
+      }
+      const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + cl * 4);
+      float4 g = *reinterpret_cast<const float4*>(dy + r * ldy + cl * 4);
+      if (act != OFX_ACT_NONE) {
+        const float4 m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + cl * 4);
+        const float4 rs = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + cl * 4);
+        g.x *= ofx_act_grad((xv.x - m.x) * rs.x * ww.x + bb.x, act);
+        g.y *= ofx_act_grad((xv.y - m.y) * rs.y * ww.y + bb.y, act);
+        g.z *= ofx_act_grad((xv.z - m.z) * rs.z * ww.z + bb.z, act);
+        g.w *= ofx_act_grad((xv.w - m.w) * rs.w * ww.w + bb.w, act);
+      }
+      s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+      q[0] += g.x * xv.x; q[1] += g.y * xv.y; q[2] += g.z * xv.z; q[3] += g.w * xv.w;
     }
-    s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
-    q[0] += g.x * xv.x; q[1] += g.y * xv.y; q[2] += g.z * xv.z; q[3] += g.w * xv.w;
   }
-  flush();
+  sb[threadIdx.x] = (rl < RP) ? cb : -1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sv[threadIdx.x][k] = s[k]; sv[threadIdx.x][4 + k] = q[k]; }
+  __syncthreads();
+  if (rl == 0) {
+    double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+    for (int j = 0; j < RP; ++j) {
+      const int t = j * CT + cl;
+      const int b = sb[t];
+      if (b < 0) continue;
+      if (b == cb) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ds[k] += (double)sv[t][k]; dq[k] += (double)sv[t][4 + k]; }
+      } else {
+        flush_direct(b, &sv[t][0], &sv[t][4]);
+      }
+    }
+    if (cb >= 0) {
+      double* o = sums + ((int64_t)cb * C + cl * 4) * 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { unsafeAtomicAdd(o + 2 * k, ds[k]); unsafeAtomicAdd(o + 2 * k + 1, dq[k]); }
+    }
+  }
 }
 
 __global__ void gn_bwd_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ count, int B, int C,
@@ -333,7 +365,7 @@ extern "C" int ofx_gn_backward(const float* x, int64_t ldx, const float* dy, int
   hipStream_t st = ofx_stream(stream);
   if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)batch_size * C, st) != hipSuccess) return OFX_ELAUNCH;
   if (n > 0)
-    gn_bwd_stats_kernel<<<(int)ofx_cdiv(n, 64), 256, 0, st>>>(x, ldx, dy, ldy, n, C, batch_id, mean, rstd, w, bias, act, sums);
+    gn_bwd_stats_kernel<<<(int)ofx_cdiv(n, GN_ROWS_PER_BLOCK), 256, 0, st>>>(x, ldx, dy, ldy, n, C, batch_id, mean, rstd, w, bias, act, sums);
   const int work = batch_size * groups > C ? batch_size * groups : C;
   gn_bwd_finalize_kernel<<<(work + 63) / 64, 64, 0, st>>>(sums, count, batch_size, C, groups, count_eps, mean, rstd, w,
                                                           coef, dgamma, dbeta);

@@ -376,10 +376,13 @@ def _unpool_bwd(up, x, dout, doctree, d, G, prefix):
 
 
 @torch.no_grad()
-def hr_unet_forward_backward(net, x, doctree, unet_lr, timesteps, dy_fn, label=None):
-    """graph_unet_hr.UNet3DModel (with its nested lr net run as the middle): forward keeping intermediates, then
-    backward.  Returns (y, dx, grads of the hr net, grads of the lr net) keyed by state_dict names."""
+def hr_unet_forward_backward(net, x, doctree, unet_lr, timesteps, dy_fn, label=None, as_middle=False):
+    """graph_unet_hr.UNet3DModel: forward keeping intermediates, then backward.
+    unet_lr: the nested stage run as the middle -- a graph_unet_lr net (2-stage hr), another graph_unet_hr net
+    (3-stage feature net, graph_unet_union.py:80-92) or None (an hr net that is itself running as_middle).
+    Returns (y, dx, grads of this net, grads of the nested net) keyed by state_dict names."""
     from . import modules as M
+    from .graph_unet_lr import UNet3DModel as LrNet
     G = _Grads()
     B = doctree.batch_size
     t_emb = ops.timestep_embedding(timesteps.float(), net.model_channels)
@@ -391,30 +394,25 @@ def hr_unet_forward_backward(net, x, doctree, unet_lr, timesteps, dy_fn, label=N
     emb_act = ops.act(e2, 'silu')
     demb_act = torch.zeros_like(emb_act)
     d = net.input_depth
-    h = net.input_blocks[0](x, doctree, d)
+    h = x if as_middle else net.input_blocks[0](x, doctree, d)
     hs = [h]
     enc_tape = []
     for (kind, dd, _), module in zip(net._enc, net.input_blocks[1:]):
+        h_in = h
         if kind == 'res':
-            h_in = h
             h, s = _gres_fwd(module, h_in, emb_act, doctree, dd)
             enc_tape.append(('res', dd, module, s))
         else:
-            h_in = h
             p = M.pool_nodes(h_in, doctree, dd, module.downsample)
             h = module.conv(p, doctree, dd - 1)
             enc_tape.append(('down', dd, module, (h_in, p)))
         hs.append(h)
     dm = net._d_mid
-    h_mid_in = h
-    m1, s_m1 = _gres_fwd(net.middle_block1, h_mid_in, emb_act, doctree, dm)
     box = {}
 
-    def after_lr(h_lr):
-        """Rest of the forward from the lr output on, then the backward down to the concat; returns dL/dh_lr."""
+    def decoder(hh):
+        """Decoder forward from `hh`, output, loss gradient, decoder backward; returns dL/dhh."""
         nonlocal demb_act
-        hc = torch.cat((m1, h_lr), dim=1)
-        hh, s_m2 = _gres_fwd(net.middle_block2, hc, emb_act, doctree, dm)
         skips = list(hs)
         dec_tape = []
         for (kind, dd, _), module in zip(net._dec, net.output_blocks):
@@ -430,40 +428,54 @@ def hr_unet_forward_backward(net, x, doctree, unet_lr, timesteps, dy_fn, label=N
                 dec_tape.append(('up', dd, module, (h_in, u), 0))
         h_end = hh
         e = net.end_norm(h_end, doctree, net.input_depth, act='silu')
-        y = net.out(e, doctree, net.input_depth)
+        y = e if as_middle else net.out(e, doctree, net.input_depth)
         box['y'] = y
-        # ---------------------------------------------------------------- backward (decoder side)
         dyv = dy_fn(y)
-        de = _gconv_bwd(net.out, e, dyv, doctree, net.input_depth, G, 'out.')
+        de = dyv if as_middle else _gconv_bwd(net.out, e, dyv, doctree, net.input_depth, G, 'out.')
         dh = _dgn_bwd(net.end_norm, h_end, de, doctree, net.input_depth, 'silu', G, 'end_norm.')
         dskip = [None] * len(hs)
-        si = 0                                            # decoder pops hs from the end
-        n_res = sum(1 for t in dec_tape if t[0] == 'res')
-        consumed = n_res
+        consumed = sum(1 for t in dec_tape if t[0] == 'res')
         for idx in range(len(dec_tape) - 1, -1, -1):
             kind, dd, module, s, c_left = dec_tape[idx]
             pre = 'output_blocks.%d.' % idx
             if kind == 'res':
                 dcat, dea = _gres_bwd(module, s, emb_act, dh, doctree, dd, G, pre)
                 demb_act += dea
-                consumed -= 1                             # this block consumed skip number `consumed` (0-based pops)
+                consumed -= 1                             # the j-th res block popped hs[len(hs) - 1 - j]
                 dskip[len(hs) - 1 - consumed] = dcat[:, c_left:].contiguous()
                 dh = dcat[:, :c_left].contiguous()
             else:
                 h_in, u = s
                 du = _gconv_bwd(module.conv, u, dh, doctree, dd + 1, G, pre + 'conv.')
                 dh = _unpool_bwd(module.upsample, h_in, du, doctree, dd, G, pre + 'upsample.')
-        dhc, dea = _gres_bwd(net.middle_block2, s_m2, emb_act, dh, doctree, dm, G, 'middle_block2.')
-        demb_act += dea
-        c1 = m1.shape[1]
-        box['dm1_left'] = dhc[:, :c1].contiguous()
         box['dskip'] = dskip
-        return dhc[:, c1:].contiguous()
+        return dh
 
-    _, dm1_lr, grads_lr = lr_unet_forward_backward(unet_lr, m1, B, timesteps, after_lr, label=label, as_middle=True)
-    dm1 = box['dm1_left'] + dm1_lr
-    dh, dea = _gres_bwd(net.middle_block1, s_m1, emb_act, dm1, doctree, dm, G, 'middle_block1.')
-    demb_act += dea
+    grads_nested = {}
+    if unet_lr is None:
+        dh = decoder(h)
+    else:
+        m1, s_m1 = _gres_fwd(net.middle_block1, h, emb_act, doctree, dm)
+
+        def after_nested(h_lr):
+            nonlocal demb_act
+            hc = torch.cat((m1, h_lr), dim=1)
+            hh, s_m2 = _gres_fwd(net.middle_block2, hc, emb_act, doctree, dm)
+            dhh = decoder(hh)
+            dhc, dea = _gres_bwd(net.middle_block2, s_m2, emb_act, dhh, doctree, dm, G, 'middle_block2.')
+            demb_act += dea
+            c1 = m1.shape[1]
+            box['dm1_left'] = dhc[:, :c1].contiguous()
+            return dhc[:, c1:].contiguous()
+
+        if isinstance(unet_lr, LrNet):
+            _, dm1_n, grads_nested = lr_unet_forward_backward(unet_lr, m1, B, timesteps, after_nested, label=label,
+                                                             as_middle=True)
+        else:
+            _, dm1_n, grads_nested, _ = hr_unet_forward_backward(unet_lr, m1, doctree, None, timesteps, after_nested,
+                                                                 label=label, as_middle=True)
+        dh, dea = _gres_bwd(net.middle_block1, s_m1, emb_act, box['dm1_left'] + dm1_n, doctree, dm, G, 'middle_block1.')
+        demb_act += dea
     dskip = box['dskip']
     # ---------------------------------------------------------------- backward (encoder side)
     for k in range(len(enc_tape) - 1, -1, -1):
@@ -480,7 +492,7 @@ def hr_unet_forward_backward(net, x, doctree, unet_lr, timesteps, dy_fn, label=N
             dh = _pool_bwd(module.downsample, h_in, dp, doctree, dd, G, pre + 'downsample.')
     if dskip[0] is not None:
         dh = dh + dskip[0]
-    dx = _gconv_bwd(net.input_blocks[0], x, dh, doctree, net.input_depth, G, 'input_blocks.0.')
+    dx = dh if as_middle else _gconv_bwd(net.input_blocks[0], x, dh, doctree, net.input_depth, G, 'input_blocks.0.')
     # ---- time embedding
     de2 = demb_act * _silu_grad(e2)
     if net.num_classes is not None:
@@ -489,4 +501,4 @@ def hr_unet_forward_backward(net, x, doctree, unet_lr, timesteps, dy_fn, label=N
         G.add('label_emb.weight', gl)
     da1 = _linear_bwd(net.time_embed[2], a1, de2, G, 'time_embed.2.')
     _linear_bwd(net.time_embed[0], t_emb, da1 * _silu_grad(e1), G, 'time_embed.0.')
-    return box['y'], dx, dict(G), grads_lr
+    return box['y'], dx, dict(G), grads_nested

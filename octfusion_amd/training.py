@@ -71,11 +71,13 @@ def lr_stage_step(net, opt, split_small, times=None, noise=None, label=None, ema
 
 
 @torch.no_grad()
-def hr_stage_step(net, opt, codes, doctree, depth, times=None, noise=None, label=None, ema=None, ema_rate=0.999):
-    """One optimisation step of the second (hr) stage, eps objective (octfusion_model_union.py:242-269 with
-    df_type 'eps'): codes [N, C] = latent codes on the depth-`depth` dual graph (GraphVAE.encode), net = the union
-    UNet3DModel (hr + nested lr); `opt` holds the parameters of both nets under their union state_dict names.
-    Returns the loss."""
+def hr_stage_step(net, opt, codes, doctree, depth, times=None, noise=None, label=None, ema=None, ema_rate=0.999,
+                  stage='hr', df_type='eps'):
+    """One optimisation step of a sparse stage (octfusion_model_union.py:242-269 / octfusion_model_union_3t.py):
+    stage 'hr' = the hr net with the lr net nested, stage 'feature' = the feature net with the hr net nested;
+    df_type 'eps' regresses the noise, 'x0' the clean data.  data [N, C] lives on the depth-`depth` dual graph
+    (latent codes from GraphVAE.encode, or split codes); net = the union UNet3DModel; `opt` holds the parameters
+    under their union state_dict names.  Returns the loss."""
     B = doctree.batch_size
     dev = codes.device
     if times is None:
@@ -88,13 +90,17 @@ def hr_stage_step(net, opt, codes, doctree, depth, times=None, noise=None, label
     noised = (alpha[bid].unsqueeze(1) * codes + sigma[bid].unsqueeze(1) * noise).contiguous()
     box = {}
 
+    target = noise if df_type == 'eps' else codes
+
     def dy_fn(y):
-        diff = y - noise
+        diff = y - target
         box['loss'] = float((diff * diff).mean())
         return diff * (2.0 / diff.numel())
-    _, _, g_hr, g_lr = BW.hr_unet_forward_backward(net.unet_hr, noised, doctree, net.unet_lr, log_snr, dy_fn, label=label)
-    grads = {'unet_hr.' + k: v for k, v in g_hr.items()}
-    grads.update({'unet_lr.' + k: v for k, v in g_lr.items()})
+    outer, nested = ('unet_hr', 'unet_lr') if stage == 'hr' else ('unet_feature', 'unet_hr')
+    _, _, g_o, g_n = BW.hr_unet_forward_backward(getattr(net, outer), noised, doctree, getattr(net, nested), log_snr,
+                                                 dy_fn, label=label)
+    grads = {outer + '.' + k: v for k, v in g_o.items()}
+    grads.update({nested + '.' + k: v for k, v in g_n.items()})
     # parameters that take no part in this stage (the lr net's own input / output convolutions) keep a zero gradient
     for k, p in opt.params.items():
         if k not in grads:

@@ -588,6 +588,57 @@ def test_hr_unet_backward_vs_autograd(golden):
         assert err <= 5e-3 * float(ref.abs().max()) + 2e-5 * gmax, (k, err, float(ref.abs().max()), gmax)
 
 
+def test_feature_unet_backward_vs_autograd(golden):
+    """3-stage cascade: the feature net with the hr net nested as its middle (itself running as_middle, without an
+    lr net) -- forward + backward against autograd through the oracle, all parameters that take part."""
+    from octfusion_amd import graph_unet_union as U, backward as BW
+    from octfusion_amd.octree import split2octree_large
+    from octfusion_amd.dual_octree import DualOctree
+    from oracle import dual_octree as OD, modules as OM, sampler as OS, unet as OU
+    G = golden('g_unet')
+    r = G['feature']
+    oc, _ = small(G['split_small'])
+    doc_l = DualOctree(split2octree_large(oc, r['split_large'].to(dev()), 5))
+    o_doc = OD.OracleDualOctree(OS.split2octree_large(OS.split2octree_small(G['split_small'], 5, 3), r['split_large'], 5))
+    o_doc.post_processing_for_docnn()
+    cfg = r['cfg']
+    sd = C.fill_state_dict(r['keys'])
+    net = load(U.UNet3DModel(**cfg), r['keys'])
+    N = doc_l.total_num
+    x = C.rand_input('ftb_x', N, 3)
+    dy = C.rand_input('ftb_dy', N, 3)
+    t = torch.tensor([-0.4, 0.7])
+
+    feat = dict(input_depth=7, full_depth=3, model_channels=cfg['model_channels'][2],
+                channel_mult=cfg['channel_mult'][2], num_res_blocks=cfg['num_res_blocks'][2], num_classes=None)
+    mid = dict(kind='hr', input_depth=5, full_depth=3, model_channels=cfg['model_channels'][1],
+               channel_mult=cfg['channel_mult'][1], num_res_blocks=cfg['num_res_blocks'][1], num_classes=None)
+    with torch.enable_grad():
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xg = x.clone().requires_grad_(True)
+        y = OU.hr_forward(OM._sub(sdg, 'unet_feature'), feat, xg, o_doc, t, None, OM._sub(sdg, 'unet_hr'), mid)
+        (y * dy).sum().backward()
+    yy, dx, g_ft, g_hr = BW.hr_unet_forward_backward(net.unet_feature, x.to(dev()), doc_l, net.unet_hr, t.to(dev()),
+                                                     lambda out: dy.to(dev()))
+    close(yy, y.detach(), 1e-3)
+    close(dx, xg.grad, 5e-3)
+    # and one optimisation step of the feature stage runs (x0 objective, Objaverse-style)
+    from octfusion_amd import training as TR
+    opt = TR.AdamW(dict(net.named_parameters()), lr=1e-3)
+    l0 = TR.hr_stage_step(net, opt, x.to(dev()), doc_l, 7, stage='feature', df_type='x0')
+    assert l0 == l0 and l0 > 0
+    net.load_state_dict(sd)                               # restore for the gradient comparison below
+    grads = {'unet_feature.' + k: v for k, v in g_ft.items()}
+    grads.update({'unet_hr.' + k: v for k, v in g_hr.items()})
+    used = {k for k in sd if sdg[k].grad is not None}
+    assert set(grads) == used, (set(grads) ^ used)
+    gmax = max(float(sdg[k].grad.abs().max()) for k in used)
+    for k in used:
+        ref = sdg[k].grad
+        err = float((grads[k].cpu() - ref).abs().max())
+        assert err <= 5e-3 * float(ref.abs().max()) + 2e-5 * gmax, (k, err, float(ref.abs().max()), gmax)
+
+
 def test_hr_training_step(golden):
     """Second-stage training step (eps objective) on the union net: first-step loss equals the oracle's, and the
     loss falls on a fixed batch."""

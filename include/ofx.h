@@ -341,6 +341,13 @@ int ofx_gn_apply(const float* x, int64_t ldx, int64_t n, int C, const int32_t* b
                  const float* mean, const float* rstd, const float* w, const float* bias,
                  int act, float* out, int64_t ldo, void* stream);
 
+/* One-launch GroupNorm (+ activation) for layouts whose batch elements own `rows_per_batch` CONTIGUOUS rows (the
+ * dense layers of the nested lr net; modules.py:26-28 GroupNorm32 with count_eps = 0): same arithmetic as
+ * ofx_gn_stats + ofx_gn_finalize + ofx_gn_apply. */
+int ofx_gn_fused_rows(const float* x, int64_t ldx, int rows_per_batch, int batch_size, int C, int groups, float eps,
+                      float count_eps, const float* w, const float* bias, int act, float* out, int64_t ldo,
+                      void* stream);
+
 /* ---------------------------------------------------------------- glue ops */
 /* dst[dmap(i), 0:C] = src[smap(i), 0:C] for i < n (maps optional; negative skips). */
 int ofx_rows_copy(const float* src, int64_t lds, const int32_t* smap, float* dst, int64_t ldd,

@@ -122,7 +122,8 @@ class GroupNorm32(nn.GroupNorm):
     @torch.no_grad()
     def forward(self, x, gs, act=None, out=None):
         return ops.group_norm(x, gs.cache.batch_id(gs.depth), gs.cache.count(gs.depth), gs.B, self.weight,
-                              self.bias, self.num_groups, self.eps, act, out, count_eps=0.0)
+                              self.bias, self.num_groups, self.eps, act, out, count_eps=0.0,
+                              rows_per_batch=8 ** gs.depth)
 
 
 def convnormalization(channels):

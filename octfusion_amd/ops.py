@@ -380,14 +380,24 @@ def gather_mean(x, seg_ptr, col):
 
 
 def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, act=None, out=None,
-               count_eps=None, stats=None):
+               count_eps=None, stats=None, rows_per_batch=None):
     """DualOctreeGroupNorm (+ optional fused activation).  count_eps=0 gives torch.nn.GroupNorm.
-    stats: fp64 [B, C, 2] sums already produced by the epilogue of the kernel that wrote x."""
+    stats: fp64 [B, C, 2] sums already produced by the epilogue of the kernel that wrote x.
+    rows_per_batch: every batch element owns that many CONTIGUOUS rows (dense grids) -> one fused launch."""
     if count_eps is None:
         count_eps = eps
     x, ldx = _row_major(x)
     n, C = x.shape
     dev = x.device
+    if rows_per_batch is not None and stats is None and rows_per_batch * (C // groups) <= (1 << 16):
+        assert n == rows_per_batch * batch_size
+        if out is None:
+            out = torch.empty(n, C, dtype=torch.float32, device=dev)
+        out2, ldo = _row_major(out)
+        assert out2 is out
+        call('ofx_gn_fused_rows', ptr(x), ldx, rows_per_batch, batch_size, C, groups, eps, count_eps,
+             ptr(weight.detach().reshape(-1)), ptr(bias.detach().reshape(-1)), ACT[act], ptr(out), ldo, stream())
+        return out
     mean = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
     rstd = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
     if stats is not None:

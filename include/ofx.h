@@ -239,7 +239,10 @@ int ofx_graph_type_frac(const int32_t* seg_ptr, const int32_t* col, const uint8_
 /* Contraction precision (process-wide): 0 = bf16x3 (default): activations and weights are
  * split into bf16 hi+lo pairs and a*w = a_hi*w_hi + a_lo*w_hi + a_hi*w_lo runs on the bf16
  * matrix pipe with fp32 accumulation -- ~1e-5 relative to an fp32 reference at 16/3 x the
- * fp32-MFMA rate; 1 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-equal to an fma chain).
+ * fp32-MFMA rate; 1 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-equal to an fma chain);
+ * 2 = reduced precision: the planes GraphConv runs ONE fp16 MFMA per product (operands rounded to fp16,
+ * fp32 accumulate; ~5e-4 per product), every other contraction stays bf16x3.  Not thread-safe: set it
+ * before launching work, from the thread that launches.
  * A packed-weight buffer holds the fp32 pack followed by the bf16 hi|lo planes:
  * ofx_packed_floats(Kp, N) floats in total. */
 int ofx_set_precision(int mode);
@@ -284,6 +287,44 @@ int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes,
                       const float* res, int64_t ldr, float* out, int64_t ldc,
                       double* stats /* optional */, int64_t stats_ld,
                       void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- GraphConv on operand planes
+ * Second implementation of the same operator (modules.py:194-220) for the layers that carry the step's
+ * time: operands arrive PRE-SPLIT and are staged global -> LDS by DMA (csrc/ofx_gemm2.hip).
+ *  "planes", mode 2 (bf16x3): every 32-channel chunk of a row is one 128-B line
+ *      [bf16 hi x 32 | bf16 lo x 32], value = hi + lo (2^-17 relative): the bytes of the fp32 row, so a
+ *      planes tensor aliases an fp32-shaped [rows, C] buffer (row pitch = fp32 pitch, C % 32 == 0);
+ *  mode 1 (single-pass fp16, reduced precision, ofx_set_precision(2)): fp16 row-major, C % 64 == 0.
+ * ofx_planes_split: fp32 -> planes (columns C..Cpad-1 zero-filled; in place allowed for mode 2).
+ * ofx_planes_merge: planes -> fp32 (tests).
+ * ofx_gn_apply_planes: ofx_gn_apply (modules.py:311-314 + fused SiLU/GELU) writing planes; `out` may be x
+ *      itself in mode 2.
+ * ofx_pack_weights_planes: GraphConv weights [7*(cin+nt'), cout] (element (k, n) at W[k*sk + n*sn]) ->
+ *      [k tile][cout][128-B line], k order: 7*cin gathered channels direction-major, then the 7*nt node-type
+ *      rows zero-padded to a whole tile; ofx_planes_packed_bytes() bytes.
+ * ofx_graphconv_fwd_planes: as ofx_graphconv_fwd, with xp / aux / tfp planes (row pitches in BYTES, 128-B
+ *      aligned bases and pitches), aux = scratch of (n_multi + 1) rows of ldx_bytes, tfp = planes of the
+ *      type_frac slab padded to a whole chunk (NULL when nt <= 1), W2 = packed planes weights.
+ *      256 x 128 tiles, no split-K: meant for layers with >= ~128 tiles. */
+int ofx_planes_split(const float* x, int64_t ldx, int64_t n, int C, int Cpad, int mode, void* out,
+                     int64_t ldo_bytes, void* stream);
+int ofx_planes_merge(const void* planes, int64_t ldp_bytes, int64_t n, int C, int mode, float* out, int64_t ldo,
+                     void* stream);
+int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id, const float* mean,
+                        const float* rstd, const float* w, const float* bias, int act, int mode, void* out,
+                        int64_t ldo_bytes, void* stream);
+int64_t ofx_planes_packed_ktiles(int cin, int nt, int mode);
+int64_t ofx_planes_packed_bytes(int cin, int nt, int cout, int mode);
+int ofx_pack_weights_planes(const float* W, int64_t sk, int64_t sn, int cin, int nt, int cout, int mode, void* out,
+                            void* stream);
+int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int cin, int64_t n_nodes, const int32_t* seg_ptr,
+                             const int32_t* col, const int32_t* nbr_ext, const int32_t* multi_seg, int64_t n_multi,
+                             void* aux, const void* tfp, int64_t ldt_bytes, int nt, const void* W2, int cout,
+                             const float* bias, const float* emb, int64_t lde, const int32_t* batch_id,
+                             const float* res, int64_t ldr, float* out, int64_t ldc, double* stats /* optional */,
+                             int64_t stats_ld, void* ws, size_t ws_bytes, int mode, void* stream);
+/* scheduling variant of the planes kernel (0: DMA requests before the MFMA group, 1: interleaved) -- A/B knob */
+int ofx_set_gconv2_variant(int v);
 
 /* ---------------------------------------------------------------- dense grids
  * The nested dense U-Net (graph_unet_lr.py) in node-row layout: a full octree layer of

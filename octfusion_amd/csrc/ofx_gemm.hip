@@ -21,9 +21,7 @@
 // Small-M problems (dense 4^3 / 8^3 grids) are split along K into up to 64 slices whose
 // partial tiles go to a workspace and are summed, in slice order (deterministic), by
 // splitk_reduce_kernel, which also applies the epilogue.
-#include "ofx_common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "ofx_gemm_common.h"
 
 constexpr int BM = 128;
 constexpr int BK = 32;
@@ -31,38 +29,6 @@ constexpr int A_LD = BK + 4;
 constexpr int MODE_DENSE = 0;
 constexpr int MODE_GATHER = 1;
 
-struct GemmArgs {
-  // A (dense)
-  const float* A; int64_t lda; const int32_t* a_rows;
-  // A (gather)
-  const float* x; int64_t ldx; int cin; int ndir; int fast;   // fast: cin % 32 == 0 and aligned
-  const int32_t* nbr;                                          // [M, ndir]: >=0 row, -1 none, -2 see CSR
-  const int32_t* seg_ptr; const int32_t* col;                  // CSR by segment m*ndir+dir (for -2 entries)
-  const float* edge_w;                                         // NULL: segment MEAN; else per-edge weights, segment weighted SUM
-  const float* tf; int64_t ldt; int64_t Kf;                    // Kf = pad32(ndir*cin)
-  const int32_t* nbr_ext;                                      // fast path: [M, ndir] in [0, n_src + 1 + V)
-  const float* aux; int64_t ldaux; int64_t n_src;              // aux row 0 = zeros, rows 1.. = multi-neighbour means
-  // common
-  int64_t M, K;            // K: logical K for dense bounds; gather uses Kp only
-  const float* Wp; int64_t Kp, N;
-  const uint16_t* W16;     // bf16 hi | lo split of the packed weights ([k/8][n][8] each), or NULL
-  const float* bias;
-  const float* emb; int64_t lde; const int32_t* bid;
-  const float* res; int64_t ldr;
-  float* out; int64_t ldc; const int32_t* out_rows;
-  double* stats; int64_t stats_ld;   // optional fused GroupNorm statistics: stats[(b*stats_ld + n)*2 + {0,1}] += (v, v*v)
-  int ntm, ntn, nsplit, kt_per_split;
-  float* ws;               // split-K partials [nsplit][M][N]
-  int vec4;                // out / res / emb / bias are 16-B aligned with pitches % 4 == 0 and N % 4 == 0
-  // fused statistics, two-stage: every wave stores the (sum, sum of squares) of its 32*MI rows to
-  // stats_part[wave_row][N][2] (plain fp32 stores), stats_reduce_kernel adds them up per batch element.
-  // NULL -> fp64 atomics straight from the epilogue (870 k device-scope atomics per depth-6 launch, measured
-  // at 75 us of a 300 us kernel).
-  float* stats_part; size_t stats_part_bytes;
-};
-
-__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-__device__ __forceinline__ void f4add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
 // mean over the CSR segment (row, dir) of x[col, cc..cc+3]
 __device__ __forceinline__ float4 gather_seg4(const GemmArgs& g, int64_t row, int dir, int cc) {
@@ -141,195 +107,6 @@ __device__ __forceinline__ void load_b_tile(const GemmArgs& g, int64_t n0, int64
 }
 
 
-// Epilogue shared by the MFMA kernels.  C/D layout of the 32x32 MFMA: col = lane&31,
-// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  out = acc + bias + emb[bid[m]] + res[m]; optionally also
-// accumulates the per-(batch element, channel) sum / sum of squares of the stored values in fp64
-// (hardware global_atomic_add_f64), so the DualOctreeGroupNorm that consumes this tensor needs no
-// statistics pass of its own (reference modules.py:299-311 makes three scatter passes).
-template <int WM, int WN, int MI, int NI>
-__device__ __forceinline__ void epilogue_store_scalar(const GemmArgs& g, f32x16 (&acc)[MI][NI], int64_t m0, int64_t n0,
-                                                      int wm, int wn, int l31, int h, int split) {
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int64_t n = n0 + (wn * NI + j) * 32 + l31;
-    if (n >= g.N) continue;
-    if (g.nsplit > 1) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (m < g.M) g.ws[((int64_t)split * g.M + m) * g.N + n] = acc[i][j][r];
-        }
-      continue;
-    }
-    const float bv = g.bias ? g.bias[n] : 0.f;
-    int sb = -1;                 // statistics run: batch id, sum, sum of squares
-    float ssum = 0.f, ssq = 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= g.M) continue;
-        float v = acc[i][j][r] + bv;
-        int b = 0;
-        if (g.emb || g.stats) b = g.bid[m];
-        if (g.emb) v += g.emb[(int64_t)b * g.lde + n];
-        if (g.res) v += g.res[m * g.ldr + n];
-        if (g.stats) {
-          if (b != sb) {
-            if (sb >= 0) {
-              double* o = g.stats + ((int64_t)sb * g.stats_ld + n) * 2;
-              unsafeAtomicAdd(o, (double)ssum);
-              unsafeAtomicAdd(o + 1, (double)ssq);
-            }
-            sb = b; ssum = 0.f; ssq = 0.f;
-          }
-          ssum += v; ssq += v * v;
-        }
-        int64_t om = m;
-        if (g.out_rows) { om = g.out_rows[m]; if (om < 0) continue; }
-        g.out[om * g.ldc + n] = v;
-      }
-    }
-    if (g.stats && sb >= 0) {
-      double* o = g.stats + ((int64_t)sb * g.stats_ld + n) * 2;
-      unsafeAtomicAdd(o, (double)ssum);
-      unsafeAtomicAdd(o + 1, (double)ssq);
-    }
-  }
-}
-
-// 4 x 4 transpose across the four lanes of a quad (DPP quad_perm, no LDS): on entry lane q holds
-// v[r] = T[r][q], on exit v[c] = T[q][c].
-__device__ __forceinline__ float dpp_xor1(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float dpp_xor2(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
-}
-__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, bool q0, bool q1) {
-  float r = dpp_xor1(q0 ? v0 : v1);
-  if (q0) v0 = r; else v1 = r;
-  r = dpp_xor1(q0 ? v2 : v3);
-  if (q0) v2 = r; else v3 = r;
-  r = dpp_xor2(q1 ? v0 : v2);
-  if (q1) v0 = r; else v2 = r;
-  r = dpp_xor2(q1 ? v1 : v3);
-  if (q1) v1 = r; else v3 = r;
-}
-
-// Vectorised epilogue.  The 32x32 MFMA leaves each lane with 4 consecutive ROWS of one column per register
-// group; a quad transpose turns that into 4 consecutive COLUMNS of one row, so every global access is a
-// 16-B piece of a 128-B row segment (8 rows x 128 B per wave instruction instead of 2 rows x 128 B of
-// dwords -- measured 15-25 % of the kernel time on the depth-6 layers with the scalar stores).
-// Lane (k = l31 >> 2, q = l31 & 3, h) owns rows q + 4h + 8G + 32i (G < 4, i < MI) and columns 4k .. 4k+3.
-template <int WM, int WN, int MI, int NI>
-__device__ __forceinline__ void epilogue_store_v4(const GemmArgs& g, f32x16 (&acc)[MI][NI], int64_t m0, int64_t n0,
-                                                  int wm, int wn, int l31, int h) {
-  const int q = l31 & 3, k = l31 >> 2;
-  const bool q0 = q & 1, q1 = q & 2;
-  const int64_t mw = m0 + wm * MI * 32;                     // first row of this wave
-  const int64_t blockIdx_tm = m0 / (WM * MI * 32);          // row-tile index of the block
-  // batch ids of this lane's rows; wave-uniform batch id -> statistics are reduced across the wave first
-  int bids[MI][4];
-  bool uni = true;
-  int b0 = 0;
-  if (g.emb || g.stats) {
-    const int64_t mlast = g.M - 1;
-    b0 = g.bid[mw < mlast ? mw : mlast];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int G = 0; G < 4; ++G) {
-        const int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
-        bids[i][G] = g.bid[m < mlast ? m : mlast];
-        uni = uni && (bids[i][G] == b0);
-      }
-    uni = __all(uni);
-  }
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
-    const bool ncol = n < g.N;                              // N % 4 == 0: the whole float4 is in or out
-    float4 bv = f4zero();
-    if (g.bias && ncol) bv = *reinterpret_cast<const float4*>(g.bias + n);
-    float4 ssum = f4zero(), ssq = f4zero();
-    int sb = -1;
-    auto flush = [&](int b) {
-      double* o = g.stats + ((int64_t)b * g.stats_ld + n) * 2;
-      unsafeAtomicAdd(o + 0, (double)ssum.x); unsafeAtomicAdd(o + 1, (double)ssq.x);
-      unsafeAtomicAdd(o + 2, (double)ssum.y); unsafeAtomicAdd(o + 3, (double)ssq.y);
-      unsafeAtomicAdd(o + 4, (double)ssum.z); unsafeAtomicAdd(o + 5, (double)ssq.z);
-      unsafeAtomicAdd(o + 6, (double)ssum.w); unsafeAtomicAdd(o + 7, (double)ssq.w);
-    };
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      float4 t[4];
-#pragma unroll
-      for (int G = 0; G < 4; ++G) {                         // every lane takes part in the transposes
-        float v0 = acc[i][j][4 * G], v1 = acc[i][j][4 * G + 1], v2 = acc[i][j][4 * G + 2], v3 = acc[i][j][4 * G + 3];
-        quad_transpose(v0, v1, v2, v3, q0, q1);
-        t[G] = make_float4(v0 + bv.x, v1 + bv.y, v2 + bv.z, v3 + bv.w);
-      }
-#pragma unroll
-      for (int G = 0; G < 4; ++G) {
-        const int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
-        if (m >= g.M || !ncol) continue;
-        float4 v = t[G];
-        if (g.emb) f4add(v, *reinterpret_cast<const float4*>(g.emb + (int64_t)bids[i][G] * g.lde + n));
-        if (g.res) f4add(v, *reinterpret_cast<const float4*>(g.res + m * g.ldr + n));
-        if (g.stats) {
-          const int b = bids[i][G];
-          if (!uni && b != sb) {
-            if (sb >= 0) flush(sb);
-            ssum = f4zero(); ssq = f4zero();
-          }
-          sb = b;
-          f4add(ssum, v);
-          ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
-        }
-        int64_t om = m;
-        if (g.out_rows) { om = g.out_rows[m]; if (om < 0) continue; }
-        *reinterpret_cast<float4*>(g.out + om * g.ldc + n) = v;
-      }
-    }
-    if (g.stats) {
-      if (uni) {
-        // one batch element in this wave's 32*MI rows: add up the 8 lanes (q, h) that share these columns
-        // (lanes without a valid row hold zeros)
-#define OFX_RED(f) f += dpp_xor1(f); f += dpp_xor2(f); f += __shfl_xor(f, 32);
-        OFX_RED(ssum.x) OFX_RED(ssum.y) OFX_RED(ssum.z) OFX_RED(ssum.w)
-        OFX_RED(ssq.x) OFX_RED(ssq.y) OFX_RED(ssq.z) OFX_RED(ssq.w)
-#undef OFX_RED
-        if (q == 0 && h == 0 && ncol && mw < g.M) {
-          if (g.stats_part) {
-            float* o = g.stats_part + (((int64_t)blockIdx_tm * WM + wm) * g.N + n) * 2;
-            *reinterpret_cast<float4*>(o) = make_float4(ssum.x, ssq.x, ssum.y, ssq.y);
-            *reinterpret_cast<float4*>(o + 4) = make_float4(ssum.z, ssq.z, ssum.w, ssq.w);
-          } else {
-            flush(b0);
-          }
-        }
-      } else {
-        if (sb >= 0 && ncol) flush(sb);
-        if (g.stats_part && q == 0 && h == 0 && ncol && mw < g.M) {      // mixed wave: its slot must read as zero
-          float* o = g.stats_part + (((int64_t)blockIdx_tm * WM + wm) * g.N + n) * 2;
-          *reinterpret_cast<float4*>(o) = f4zero();
-          *reinterpret_cast<float4*>(o + 4) = f4zero();
-        }
-      }
-    }
-  }
-}
-
-template <int WM, int WN, int MI, int NI>
-__device__ __forceinline__ void epilogue_store(const GemmArgs& g, f32x16 (&acc)[MI][NI], int64_t m0, int64_t n0, int wm,
-                                               int wn, int l31, int h, int split) {
-  if (g.vec4 && g.nsplit == 1) epilogue_store_v4<WM, WN, MI, NI>(g, acc, m0, n0, wm, wn, l31, h);
-  else epilogue_store_scalar<WM, WN, MI, NI>(g, acc, m0, n0, wm, wn, l31, h, split);
-}
 
 template <int MODE, int WM, int WN, int MI, int NI>
 __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
@@ -1082,9 +859,11 @@ static int pack_bf16x3(const float* Wp, int64_t Kp, int64_t N, hipStream_t st) {
   return OFX_OK;
 }
 
-static int g_precision = 0;     // 0: bf16x3 on the bf16 matrix pipe (default), 1: exact fp32 MFMA
+// 0: bf16x3 on the bf16 matrix pipe (default), 1: exact fp32 MFMA, 2: fp16 single pass in the planes GraphConv
+// (ofx_gemm2.hip), bf16x3 here.  Process-wide and unsynchronised: set it from the launching thread between launches.
+static int g_precision = 0;
 extern "C" int ofx_set_precision(int mode) {
-  if (mode != 0 && mode != 1) return OFX_EINVAL;
+  if (mode < 0 || mode > 2) return OFX_EINVAL;
   g_precision = mode;
   return OFX_OK;
 }
@@ -1241,6 +1020,15 @@ __global__ void __launch_bounds__(256) stats_reduce_kernel(const float* __restri
   }
 }
 
+// second stage of the fused statistics for a launch whose waves own `wr_rows` rows each (also used by ofx_gemm2.hip)
+int ofx_launch_stats_reduce(const GemmArgs& g, int wr_rows, hipStream_t st) {
+  const int64_t nwr = ofx_cdiv(g.M, wr_rows);
+  stats_reduce_kernel<<<dim3((unsigned)ofx_cdiv(nwr, 64), (unsigned)ofx_cdiv(g.N, 64)), 256, 0, st>>>(
+      g.stats_part, nwr, wr_rows, g.N, g.bid, g.stats, g.stats_ld);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
 template <int MODE>
 static int launch_gemm(GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0) return OFX_OK;
@@ -1276,7 +1064,7 @@ static int launch_gemm(GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st) 
     fast = ((g.lda & 3) == 0) && ((g.K & 3) == 0) && g.K >= 4 && ((((uintptr_t)g.A) & 15) == 0);
     if (fast) { g.ndir = 1; g.n_src = 0; g.aux = g.A; g.tf = g.A; g.ldt = g.lda; g.nbr_ext = (const int32_t*)g.A; }
   }
-  g.W16 = (g_precision == 0) ? reinterpret_cast<const uint16_t*>(g.Wp + g.Kp * g.N) : nullptr;
+  g.W16 = (g_precision != 1) ? reinterpret_cast<const uint16_t*>(g.Wp + g.Kp * g.N) : nullptr;
   const int wr_rows = bn == 32 ? 32 : 64;                   // rows per wave in the three tile configurations
   const int64_t nwr = ofx_cdiv(g.M, wr_rows);
   if (!(g.stats && g.vec4 && nsplit == 1 && g.stats_part &&
@@ -1295,9 +1083,10 @@ static int launch_gemm(GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st) 
   else rc = launch_cfg<MODE, 2, 2, 2, 2>(g, st);
   if (rc) return rc;
   if (nsplit > 1) splitk_reduce_kernel<<<ofx_grid(g.M * g.N, 256), 256, 0, st>>>(g);
-  if (g.stats_part)
-    stats_reduce_kernel<<<dim3((unsigned)ofx_cdiv(nwr, 64), (unsigned)ofx_cdiv(g.N, 64)), 256, 0, st>>>(
-        g.stats_part, nwr, wr_rows, g.N, g.bid, g.stats, g.stats_ld);
+  if (g.stats_part) {
+    rc = ofx_launch_stats_reduce(g, wr_rows, st);
+    if (rc) return rc;
+  }
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
@@ -1697,7 +1486,7 @@ __global__ void __launch_bounds__(256, 2) tn_gemm_kernel(const TnArgs a) {
 
 template <bool DENSE_P>
 static void launch_tn(const TnArgs& a, dim3 grid, hipStream_t st) {
-  if (g_precision == 0) tn_gemm_kernel<DENSE_P, true><<<grid, 256, 0, st>>>(a);
+  if (g_precision != 1) tn_gemm_kernel<DENSE_P, true><<<grid, 256, 0, st>>>(a);
   else tn_gemm_kernel<DENSE_P, false><<<grid, 256, 0, st>>>(a);
 }
 

@@ -1,0 +1,668 @@
+// libofx: fused dual-octree GraphConv on PRE-SPLIT operand planes, staged by LDS-DMA.
+//
+// Why a second contraction kernel.  The register-staged 128 x 128 kernel (ofx_gemm.hip) moves, per 96 MFMAs,
+// 16 KB of gathered fp32 rows + 32 KB of weight fragments from L2 through the CU's vector-memory path, splits
+// the rows to bf16 in VALU and writes them to LDS with ds_write: it sits at the balance point of the 64 B/clk
+// L2->CU path, the LDS write path and the matrix pipe (~0.30 of the bf16x3 roof).  This
+// kernel spends fewer operand bytes per MFMA and no VALU / ds_write / staging registers at all:
+//   * activations arrive already split: the producer (ofx_gn_apply_planes, ofx_planes_split) writes, for every
+//     32-channel chunk of a row, one 128-B line [hi k0..31 | lo k0..31] (bf16 pair, a = hi + lo to 2^-17) --
+//     the same bytes as the fp32 row, so the planes alias fp32-shaped buffers (zero-copy concat still works);
+//     in the single-pass fp16 mode a line is 64 fp16 channels;
+//   * weights are packed once as [k tile][column][128 B] lines of the same shape;
+//   * a block is 256 rows x 128 columns, 8 waves (4 x 2 wave tiles of 64 x 64), ONE block per CU; per k-step it
+//     stages 256 A lines (gathered through the neighbour table) + 128 B lines = 48 KB with
+//     global_load_lds_dwordx4 (global -> LDS, no registers), i.e. half the bytes per MFMA of the old kernel;
+//   * the LDS image is lane-linear per DMA instruction (hardware rule), so the 16-B piece a lane fetches is
+//     XOR-swizzled on the SOURCE side (piece ^= (row >> 1) & 7): the MFMA fragment reads (ds_read_b128, 16
+//     different rows per lane group) are then bank-conflict free;
+//   * three LDS stage buffers, DMA two k-steps ahead, counted vmcnt, one raw s_barrier per k-step placed in the
+//     MIDDLE of the step's MFMAs; the fragment registers are double-buffered by half steps so the LDS reads of
+//     the next half always overlap the current half's MFMAs;
+//   * the neighbour-table slice of the tile lives in LDS (an ordinary global load in the loop would make
+//     hipcc drain the DMA queue at its use).
+// Contraction: PREC 2 = bf16x3 (a_lo*w_hi + a_hi*w_lo + a_hi*w_hi on v_mfma_f32_32x32x16_bf16, fp32
+// accumulate: same arithmetic as ofx_gemm.hip's default), PREC 1 = one v_mfma_f32_32x32x16_f16 per product
+// (operands rounded to fp16: ~5e-4 per product, reduced-precision mode for BASELINE configs[4]).
+// The epilogue (bias / time-embedding / residual / fused GroupNorm statistics) is shared with ofx_gemm.hip.
+#include "ofx_gemm_common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const char __attribute__((address_space(1)))* gcp;
+typedef __attribute__((address_space(3))) void* ldsp;
+
+constexpr int G2_BM = 256, G2_BN = 128;
+constexpr int G2_WM = 4, G2_WN = 2, G2_MI = 2, G2_NI = 2;
+constexpr int G2_LINE = 128;                          // bytes per row per k-step (both precisions)
+constexpr int G2_A_BYTES = G2_BM * G2_LINE;           // 32 KB
+constexpr int G2_B_BYTES = G2_BN * G2_LINE;           // 16 KB
+constexpr int G2_BUF = G2_A_BYTES + G2_B_BYTES;       // 48 KB per stage
+constexpr int G2_NBUF = 3;
+constexpr int G2_TAB = G2_NBUF * G2_BUF;              // neighbour-table slice [256][8] uint32
+constexpr int G2_LDS = G2_TAB + G2_BM * 8 * 4;        // 155 648 B (of 163 840)
+
+struct Gemm2Args {
+  const char* xp; int64_t ldx;            // activation planes; row pitch in BYTES
+  const char* aux;                        // rows n_src.. of the id space: [0] zeros, [1 + v] multi-neighbour means
+  int64_t n_src;
+  const int32_t* nbr_ext;                 // [M, 7]
+  const char* tfp; int64_t ldt;           // node-type slab planes (row pitch bytes) or the activation planes again
+  const char* W2;                         // [nkt][N][128 B]
+  int tpd, nkt_g, nkt;                    // k tiles per direction, gather tiles (7 * tpd), all tiles
+  GemmArgs e;                             // M, N, epilogue operands, tile grid
+};
+
+template <int PREC> struct G2Frag;
+template <> struct G2Frag<2> { typedef bf16x8_t T; };
+template <> struct G2Frag<1> { typedef f16x8_t T; };
+
+template <int PREC>
+__device__ __forceinline__ f32x16 g2_mfma(typename G2Frag<PREC>::T a, typename G2Frag<PREC>::T b, f32x16 c);
+template <>
+__device__ __forceinline__ f32x16 g2_mfma<2>(bf16x8_t a, bf16x8_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16 g2_mfma<1>(f16x8_t a, f16x8_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// ---- LDS reads of the k-loop are INLINE ASM with hand-counted waits.  With a global_load_lds anywhere in a loop
+// hipcc's waitcnt pass stops counting LDS reads and puts `s_waitcnt lgkmcnt(0)` in front of every consumer (checked
+// on a 40-line reproducer), which would serialise the fragment reads of the next half step with the MFMAs of the
+// current one.  Every wait names the registers it guards as "+v" operands, so no consumer can be scheduled above it.
+template <int OFF, typename T>
+__device__ __forceinline__ void g2_ds_read128(T& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void g2_ds_read32(uint32_t& d, unsigned addr) {
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+// half-step fragment set: two piece classes of every A / B fragment of the 64 x 64 wave tile
+template <int PREC> struct G2Half { typename G2Frag<PREC>::T a[2][G2_MI], b[2][G2_NI]; };
+#define G2_HALF_OPS(F)                                                                                        \
+  "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[0][1]),      \
+      "+v"(F.b[1][0]), "+v"(F.b[1][1])
+// wait until at most N younger LDS reads of this wave are outstanding; guards fragment set F
+template <int N, int PREC>
+__device__ __forceinline__ void g2_wait_lgkm(G2Half<PREC>& F) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : G2_HALF_OPS(F) : "n"(N));
+}
+struct G2Idx { uint32_t v[4]; };
+template <int N>
+__device__ __forceinline__ void g2_wait_lgkm(G2Idx& I) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(I.v[0]), "+v"(I.v[1]), "+v"(I.v[2]), "+v"(I.v[3]) : "n"(N));
+}
+// wait for all but the newest VM DMA instructions of this wave and for ALL its LDS reads (guarding F), then meet
+// the block.  The memory clobber keeps DMA issues and LDS traffic on their side of the barrier.
+template <int VM, int PREC>
+__device__ __forceinline__ void g2_wait_barrier(G2Half<PREC>& F) {
+  asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)\n\ts_barrier" : G2_HALF_OPS(F) : "n"(VM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void g2_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
+}
+
+constexpr int G2_GLDS_PER_STEP = 6;                   // DMA instructions per wave per k-step (4 A + 2 B)
+
+template <int PREC, int VARIANT>
+__global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
+  typedef G2Half<PREC> Half;
+  extern __shared__ __attribute__((aligned(128))) char smem2[];
+  const GemmArgs& g = a.e;
+
+  const int ntile = g.ntm * g.ntn;
+  int bid = blockIdx.x;
+  {   // XCD-aware bijective tile order: consecutive row tiles (Morton neighbours) share one XCD's L2
+    const int q = ntile / 8, r = ntile % 8, xcd = bid % 8, j = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tm = bid / g.ntn, tn = bid - tm * g.ntn;
+  const int64_t m0 = (int64_t)tm * G2_BM, n0 = (int64_t)tn * G2_BN;
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // ---- neighbour-table slice of this row tile -> LDS, already translated to unsigned 128-B LINE offsets:
+  //   tab[r][d < 7] = line offset of source row nbr_ext[m, d] from xlo = min(xp, aux) (rows >= n_src live in `aux`),
+  //   tab[r][7]     = line offset of the tile row's own node-type slab row from tfp.
+  // (32 bits of line offset span 512 GB)
+  const char* const xlo = a.xp < a.aux ? a.xp : a.aux;
+  {
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem2 + G2_TAB);
+    const int64_t mmax = g.M - 1;
+    const int64_t lpr = a.ldx >> 7, lpt = a.ldt >> 7;          // lines per row
+    const int64_t x_line = (a.xp - xlo) >> 7, aux_line = (a.aux - xlo) >> 7;   // all 128-B aligned (host-checked)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int e = threadIdx.x + 512 * t;
+      const int r = e >> 3, d = e & 7;
+      int64_t m = m0 + r;
+      m = m < mmax ? m : mmax;
+      int64_t line;
+      if (d < 7) {
+        const int64_t id = a.nbr_ext[m * 7 + d];
+        line = id < a.n_src ? x_line + id * lpr : aux_line + (id - a.n_src) * lpr;
+      } else {
+        line = m * lpt;
+      }
+      tab[e] = (uint32_t)line;
+    }
+  }
+  __syncthreads();
+
+  // ---- wave-uniform loop operands pinned in SGPRs
+  auto sgpr32 = [](int v) {
+    int r = __builtin_amdgcn_readfirstlane(v);
+    asm volatile("" : "+s"(r));
+    return r;
+  };
+  auto sgpr64 = [](uint64_t v) {
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return ((uint64_t)hi << 32) | lo;
+  };
+  const int64_t wstep = (int64_t)sgpr64((uint64_t)(g.N * (int64_t)G2_LINE));   // bytes per k tile of the packed weights
+  const int tpd = sgpr32(a.tpd), nkt_g = sgpr32(a.nkt_g), nkt = sgpr32(a.nkt);
+  const gcp xp_s = (gcp)sgpr64((uint64_t)xlo), tfp_s = (gcp)sgpr64((uint64_t)a.tfp);
+  const unsigned lds0 = (unsigned)(uintptr_t)(ldsp)smem2;    // LDS byte address of the dynamic segment
+
+  // ---- per-lane DMA source state
+  const int q8 = lane & 7, rsub = lane >> 3;                 // slot within the line, row within the 8-row piece
+  // rows handled by this lane: A rows wid*32 + j*8 + rsub (j < 4), B columns wid*16 + j*8 + rsub (j < 2);
+  // (row >> 1) & 7 == (j*4 + (lane >> 4)) & 7 for both
+  const int swz0 = (lane >> 4) & 7, swz1 = (4 + (lane >> 4)) & 7;
+  const int pa0 = (q8 ^ swz0) * 16, pa1 = (q8 ^ swz1) * 16;  // byte offset of the piece this lane fetches (j even / odd)
+  const unsigned tab_lane = lds0 + G2_TAB + (wid * 32 + rsub) * 32;      // + j*256 + column*4
+  gcp wb0, wb1;
+  {
+    const int64_t Nc = g.N;
+    int64_t c0 = n0 + wid * 16 + rsub, c1 = c0 + 8;
+    c0 = c0 < Nc ? c0 : Nc - 1;
+    c1 = c1 < Nc ? c1 : Nc - 1;
+    wb0 = (gcp)a.W2 + c0 * G2_LINE + pa0;
+    wb1 = (gcp)a.W2 + c1 * G2_LINE + pa1;
+  }
+
+  // description of one k tile for the DMA stream (all wave-uniform)
+  struct Tile { int tcol; int ktw; gcp base; };      // table column, packed-weight tile, source base + chunk offset
+  // table entries of the tile for this lane's four A rows (4 LDS reads)
+  auto load_idx = [&](const Tile& T, G2Idx& I) {
+    const unsigned ad = tab_lane + T.tcol * 4;
+    g2_ds_read32<0>(I.v[0], ad);
+    g2_ds_read32<256>(I.v[1], ad);
+    g2_ds_read32<512>(I.v[2], ad);
+    g2_ds_read32<768>(I.v[3], ad);
+  };
+  // request the tile into the stage buffer at byte offset `ob` (6 DMA instructions)
+  auto issue = [&](const Tile& T, int ob, const G2Idx& I) {
+    const gcp b0 = T.base + pa0, b1 = T.base + pa1;
+    char* const abuf = smem2 + ob + wid * (32 * G2_LINE);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds(((j & 1) ? b1 : b0) + ((uint64_t)I.v[j] << 7),
+                                       (ldsp)(abuf + j * (8 * G2_LINE)), 16, 0, 0);
+    char* const bbuf = smem2 + ob + G2_A_BYTES + wid * (16 * G2_LINE);
+    const int64_t wo = (int64_t)T.ktw * wstep;
+    __builtin_amdgcn_global_load_lds(wb0 + wo, (ldsp)(bbuf), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(wb1 + wo, (ldsp)(bbuf + 8 * G2_LINE), 16, 0, 0);
+  };
+  // tile `it` of the k order: channel chunk outer, direction inner over the 7 * tpd gather tiles, then the
+  // node-type tiles (prologue only: the loops below advance (dir, chunk) incrementally)
+  auto tile_of = [&](int it) {
+    Tile T;
+    if (it < nkt_g) {
+      const int chunk = it / 7, dir = it - chunk * 7;
+      T.tcol = dir; T.ktw = dir * tpd + chunk; T.base = xp_s + (int64_t)chunk * G2_LINE;
+    } else {
+      T.tcol = 7; T.ktw = it; T.base = tfp_s + (int64_t)(it - nkt_g) * G2_LINE;
+    }
+    return T;
+  };
+
+  // ---- per-lane fragment read state: piece class t (= 0..3) of row l31 sits at ((2t + h) ^ s) * 16, s = (l31 >> 1) & 7
+  //   PREC 2: half c holds {hi, lo} of k 16c..16c+15   (classes c and 2 + c)
+  //   PREC 1: half c holds k 32c..32c+31               (classes 2c and 2c + 1)
+  const int s7 = (l31 >> 1) & 7;
+  unsigned fa[2][2], fb[2][2];                       // [half][class within the half]: LDS byte addresses in stage 0
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = PREC == 2 ? (u == 0 ? c : 2 + c) : 2 * c + u;
+      const int po = ((2 * t + h) ^ s7) * 16;
+      fa[c][u] = lds0 + (wm * 64 + l31) * G2_LINE + po;
+      fb[c][u] = lds0 + G2_A_BYTES + (wn * 64 + l31) * G2_LINE + po;
+    }
+  // 8 LDS reads: half c of the tile staged at byte offset ob
+  auto read_half = [&](int ob, int c, Half& F) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      g2_ds_read128<0>(F.a[u][0], fa[c][u] + ob);
+      g2_ds_read128<32 * G2_LINE>(F.a[u][1], fa[c][u] + ob);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      g2_ds_read128<0>(F.b[u][0], fb[c][u] + ob);
+      g2_ds_read128<32 * G2_LINE>(F.b[u][1], fb[c][u] + ob);
+    }
+  };
+
+  f32x16 acc[G2_MI][G2_NI];
+#pragma unroll
+  for (int i = 0; i < G2_MI; ++i)
+#pragma unroll
+    for (int j = 0; j < G2_NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto mfma_half = [&](const Half& F) {
+    if (PREC == 2) {
+      // [0] = hi, [1] = lo: small cross terms first, the leading term last
+#pragma unroll
+      for (int i = 0; i < G2_MI; ++i)
+#pragma unroll
+        for (int j = 0; j < G2_NI; ++j) acc[i][j] = g2_mfma<PREC>(F.a[1][i], F.b[0][j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < G2_MI; ++i)
+#pragma unroll
+        for (int j = 0; j < G2_NI; ++j) acc[i][j] = g2_mfma<PREC>(F.a[0][i], F.b[1][j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < G2_MI; ++i)
+#pragma unroll
+        for (int j = 0; j < G2_NI; ++j) acc[i][j] = g2_mfma<PREC>(F.a[0][i], F.b[0][j], acc[i][j]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < G2_MI; ++i)
+#pragma unroll
+          for (int j = 0; j < G2_NI; ++j) acc[i][j] = g2_mfma<PREC>(F.a[t][i], F.b[t][j], acc[i][j]);
+    }
+  };
+
+#define G2_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // ---- prologue: tiles 0 and 1 in flight, tile 0 landed for everyone, its first half on its way to registers
+  Half F0, F1;
+  G2Idx I;
+  {
+    const Tile T0 = tile_of(0);
+    load_idx(T0, I);
+    g2_wait_lgkm<0>(I);
+    issue(T0, 0, I);
+  }
+  if (nkt > 1) {
+    const Tile T1 = tile_of(1);
+    load_idx(T1, I);
+    g2_wait_lgkm<0>(I);
+    issue(T1, G2_BUF, I);
+    g2_wait_barrier<G2_GLDS_PER_STEP>();
+  } else {
+    g2_wait_barrier<0>();
+  }
+  read_half(0, 0, F0);
+
+  // One k-step.  On entry: F0 = first half of tile `it` (8 reads, possibly still in flight), tile it+1 requested.
+  //   4 table reads of tile it+2 | 8 reads: second half of tile it -> F1 | wait F0 (12 younger reads) |
+  //   MFMAs of F0 interleaved with: wait table (8 younger) -> 6 DMA requests of tile it+2 |
+  //   wait (tile it+1 landed, all own LDS reads done) + barrier | 8 reads: first half of tile it+1 -> F0 | MFMAs of F1
+  // ob / obn / obnn: byte offsets of the stage buffers of tiles it, it+1, it+2 (rotating).
+  int ob = 0, obn = G2_BUF, obnn = 2 * G2_BUF;
+  auto step_issue = [&](const Tile& T) {
+    load_idx(T, I);
+    read_half(ob, 1, F1);
+    g2_wait_lgkm<12, PREC>(F0);
+    G2_FENCE();
+    g2_wait_lgkm<8>(I);
+    issue(T, obnn, I);
+    if (VARIANT == 0) {
+      G2_FENCE();
+    }
+    mfma_half(F0);
+    if (VARIANT == 1) {
+      // rounds of {2 MFMA, address arithmetic, 1 DMA}: the DMA issues ride in the MFMAs' shadow
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+    G2_FENCE();
+    g2_wait_barrier<G2_GLDS_PER_STEP, PREC>(F1);
+    G2_FENCE();
+    read_half(obn, 0, F0);
+    G2_FENCE();
+    mfma_half(F1);
+    G2_FENCE();
+    const int t = ob; ob = obn; obn = obnn; obnn = t;
+  };
+  int it = 0;
+  {   // steady state, gather tiles: tile it+2 = (chunk gc, direction gd), advanced without division
+    int gd = 2, gc = 0;                                          // nkt_g >= 7 > 2
+    for (; it + 2 < nkt_g; ++it) {
+      Tile T;
+      T.tcol = gd; T.ktw = gd * tpd + gc; T.base = xp_s + (int64_t)gc * G2_LINE;
+      step_issue(T);
+      const int wrap = gd == 6;
+      gd = wrap ? 0 : gd + 1;
+      gc += wrap;
+    }
+  }
+  for (; it + 2 < nkt; ++it) {                                   // steady state, node-type tiles
+    Tile T;
+    T.tcol = 7; T.ktw = it + 2; T.base = tfp_s + (int64_t)(it + 2 - nkt_g) * G2_LINE;
+    step_issue(T);
+  }
+  for (; it < nkt; ++it) {                       // last two tiles: nothing left to request
+    read_half(ob, 1, F1);
+    g2_wait_lgkm<8, PREC>(F0);
+    G2_FENCE();
+    mfma_half(F0);
+    G2_FENCE();
+    g2_wait_barrier<0, PREC>(F1);
+    G2_FENCE();
+    if (it + 1 < nkt) read_half(obn, 0, F0);
+    G2_FENCE();
+    mfma_half(F1);
+    G2_FENCE();
+    const int t = ob; ob = obn; obn = obnn; obnn = t;
+  }
+#undef G2_FENCE
+
+  epilogue_store<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, m0, n0, wm, wn, l31, h, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// plane conversion helpers
+__device__ __forceinline__ unsigned g2_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned g2_pk_f16(float a, float b) {
+  const _Float16 x = (_Float16)a, y = (_Float16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ float g2_bf16_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float g2_bf16_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+
+// fp32 [n, C] (zero-extended to Cpad columns) -> planes.  mode 2: lane q of every 8-lane group owns channels
+// 4q..4q+3 of a 32-channel chunk (one coalesced 128-B line in, 64 B hi + 64 B lo out, safe in place);
+// mode 1: fp16 row-major (8 B per lane).
+__global__ void __launch_bounds__(256) planes_split_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int C,
+                                                           int Cpad, int mode, char* __restrict__ out, int64_t ldo) {
+  const int CT = Cpad >> 2;
+  const int64_t total = n * CT;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / CT;
+    const int c = (int)(t - r * CT) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c + 3 < C) {
+      v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    } else {
+      if (c + 0 < C) v.x = x[r * ldx + c];
+      if (c + 1 < C) v.y = x[r * ldx + c + 1];
+      if (c + 2 < C) v.z = x[r * ldx + c + 2];
+    }
+    if (mode == 2) {
+      const unsigned h0 = g2_pk_bf16(v.x, v.y), h1 = g2_pk_bf16(v.z, v.w);
+      const unsigned l0 = g2_pk_bf16(v.x - g2_bf16_lo(h0), v.y - g2_bf16_hi(h0));
+      const unsigned l1 = g2_pk_bf16(v.z - g2_bf16_lo(h1), v.w - g2_bf16_hi(h1));
+      char* o = out + r * ldo + (c >> 5) * 128 + (c & 31) * 2;
+      *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(o + 64) = make_uint2(l0, l1);
+    } else {
+      *reinterpret_cast<uint2*>(out + r * ldo + c * 2) = make_uint2(g2_pk_f16(v.x, v.y), g2_pk_f16(v.z, v.w));
+    }
+  }
+}
+
+extern "C" int ofx_planes_split(const float* x, int64_t ldx, int64_t n, int C, int Cpad, int mode, void* out,
+                                int64_t ldo_bytes, void* stream) {
+  const int chunk = mode == 2 ? 32 : 64;
+  if ((mode != 1 && mode != 2) || n < 0 || C < 1 || Cpad < C || (Cpad % chunk) || ldx < C || !out ||
+      ldo_bytes < (int64_t)Cpad * (mode == 2 ? 4 : 2) || (ldo_bytes & 15) || ((uintptr_t)out & 15) || (n > 0 && !x))
+    return OFX_EINVAL;
+  if (C >= 4 && ((ldx & 3) || ((uintptr_t)x & 15))) return OFX_EINVAL;
+  if (n > 0)
+    planes_split_kernel<<<ofx_grid(n * (Cpad / 4), 256), 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, Cpad, mode,
+                                                                                      (char*)out, ldo_bytes);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+// planes -> fp32 (tests / debugging)
+__global__ void __launch_bounds__(256) planes_merge_kernel(const char* __restrict__ p, int64_t ldp, int64_t n, int C,
+                                                           int mode, float* __restrict__ out, int64_t ldo) {
+  const int64_t total = n * C;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / C;
+    const int c = (int)(t - r * C);
+    float v;
+    if (mode == 2) {
+      const unsigned short* q = reinterpret_cast<const unsigned short*>(p + r * ldp + (c >> 5) * 128 + (c & 31) * 2);
+      v = __uint_as_float((unsigned)q[0] << 16) + __uint_as_float((unsigned)q[32] << 16);
+    } else {
+      v = (float)*reinterpret_cast<const _Float16*>(p + r * ldp + c * 2);
+    }
+    out[r * ldo + c] = v;
+  }
+}
+extern "C" int ofx_planes_merge(const void* planes, int64_t ldp_bytes, int64_t n, int C, int mode, float* out,
+                                int64_t ldo, void* stream) {
+  const int chunk = mode == 2 ? 32 : 64;
+  if ((mode != 1 && mode != 2) || n < 0 || C < 1 || (C % chunk) || !planes || !out || ldo < C) return OFX_EINVAL;
+  if (n > 0)
+    planes_merge_kernel<<<ofx_grid(n * C, 256), 256, 0, ofx_stream(stream)>>>((const char*)planes, ldp_bytes, n, C,
+                                                                              mode, out, ldo);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+// aux[0] = zero row; aux[1 + v] = mean over segment multi_seg[v] of the (re-assembled) source rows, re-split.
+// One thread per (aux row, 8 channels).
+__global__ void __launch_bounds__(256) planes_multi_mean_kernel(const char* __restrict__ xp, int64_t ldx, int cin,
+                                                                const int32_t* __restrict__ seg_ptr,
+                                                                const int32_t* __restrict__ col,
+                                                                const int32_t* __restrict__ multi_seg, int64_t V,
+                                                                int mode, char* __restrict__ aux) {
+  const int c8n = cin >> 3;
+  const int64_t total = (V + 1) * c8n;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = t / c8n;
+    const int c = (int)(t - v * c8n) * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // byte offset of this 8-channel piece inside a row
+    const int64_t poff = mode == 2 ? (int64_t)(c >> 5) * 128 + (c & 31) * 2 : (int64_t)c * 2;
+    if (v > 0) {
+      const int64_t s = multi_seg[v - 1];
+      const int32_t b = seg_ptr[s], e = seg_ptr[s + 1];
+      for (int32_t p = b; p < e; ++p) {
+        const char* row = xp + (int64_t)col[p] * ldx + poff;
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(row);
+        if (mode == 2) {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(row + 64);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            acc[2 * k] += g2_bf16_lo(hi[k]) + g2_bf16_lo(lo[k]);
+            acc[2 * k + 1] += g2_bf16_hi(hi[k]) + g2_bf16_hi(lo[k]);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            acc[2 * k] += (float)__builtin_bit_cast(_Float16, (unsigned short)(hi[k] & 0xffffu));
+            acc[2 * k + 1] += (float)__builtin_bit_cast(_Float16, (unsigned short)(hi[k] >> 16));
+          }
+        }
+      }
+      const float inv = 1.f / (float)(e - b);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] *= inv;
+    }
+    char* o = aux + v * ldx + poff;
+    if (mode == 2) {
+      u32x4 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = g2_pk_bf16(acc[2 * k], acc[2 * k + 1]);
+        lo[k] = g2_pk_bf16(acc[2 * k] - g2_bf16_lo(hi[k]), acc[2 * k + 1] - g2_bf16_hi(hi[k]));
+      }
+      *reinterpret_cast<u32x4*>(o) = hi;
+      *reinterpret_cast<u32x4*>(o + 64) = lo;
+    } else {
+      u32x4 hv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hv[k] = g2_pk_f16(acc[2 * k], acc[2 * k + 1]);
+      *reinterpret_cast<u32x4*>(o) = hv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights -> [k tile][column][128-B line]; k order of the fused GraphConv: 7 x cin gathered channels
+// (direction-major), then the node-type rows padded to a whole tile.
+static inline int64_t g2_chunk(int mode) { return mode == 2 ? 32 : 64; }
+extern "C" int64_t ofx_planes_packed_ktiles(int cin, int nt, int mode) {
+  const int64_t ch = g2_chunk(mode);
+  return 7 * ((int64_t)cin / ch) + (nt > 1 ? (7 * (int64_t)nt + ch - 1) / ch : 0);
+}
+extern "C" int64_t ofx_planes_packed_bytes(int cin, int nt, int cout, int mode) {
+  return ofx_planes_packed_ktiles(cin, nt, mode) * (int64_t)cout * G2_LINE;
+}
+
+__global__ void __launch_bounds__(256) planes_pack_kernel(const float* __restrict__ W, int64_t sk, int64_t sn, int cin,
+                                                          int ntc, int64_t N, int64_t nkt, int mode,
+                                                          char* __restrict__ out) {
+  // one thread per 16-B piece: (k tile, column, piece)
+  const int64_t total = nkt * N * 8;
+  const int ch = mode == 2 ? 32 : 64;
+  const int64_t Kf = 7 * (int64_t)cin;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(t & 7);
+    const int64_t n = (t >> 3) % N, kt = (t >> 3) / N;
+    const int64_t k0 = kt * ch + (mode == 2 ? (p & 3) * 8 : p * 8);
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int64_t k = k0 + e;
+      int64_t src = -1;
+      if (k < Kf) {
+        const int64_t dir = k / cin, c = k - dir * cin;
+        src = dir * (cin + ntc) + c;
+      } else if (ntc > 0 && k - Kf < 7 * (int64_t)ntc) {
+        const int64_t kk = k - Kf, dir = kk / ntc, ty = kk - dir * ntc;
+        src = dir * (cin + ntc) + cin + ty;
+      }
+      w[e] = src >= 0 ? W[src * sk + n * sn] : 0.f;
+    }
+    u32x4 o;
+    if (mode == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned hi = g2_pk_bf16(w[2 * e], w[2 * e + 1]);
+        o[e] = p < 4 ? hi : g2_pk_bf16(w[2 * e] - g2_bf16_lo(hi), w[2 * e + 1] - g2_bf16_hi(hi));
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = g2_pk_f16(w[2 * e], w[2 * e + 1]);
+    }
+    *reinterpret_cast<u32x4*>(out + t * 16) = o;
+  }
+}
+
+extern "C" int ofx_pack_weights_planes(const float* W, int64_t sk, int64_t sn, int cin, int nt, int cout, int mode,
+                                       void* out, void* stream) {
+  if (!W || !out || (mode != 1 && mode != 2) || cin < 1 || (cin % g2_chunk(mode)) || nt < 0 || cout < 1 ||
+      ((uintptr_t)out & 15))
+    return OFX_EINVAL;
+  const int64_t nkt = ofx_planes_packed_ktiles(cin, nt, mode);
+  planes_pack_kernel<<<ofx_grid(nkt * cout * 8, 256), 256, 0, ofx_stream(stream)>>>(W, sk, sn, cin, nt > 1 ? nt : 0,
+                                                                                    cout, nkt, mode, (char*)out);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int ofx_launch_stats_reduce(const GemmArgs& g, int wr_rows, hipStream_t st);   // ofx_gemm.hip
+
+static int g2_variant = 0;
+extern "C" int ofx_set_gconv2_variant(int v) {
+  if (v < 0 || v > 1) return OFX_EINVAL;
+  g2_variant = v;
+  return OFX_OK;
+}
+
+template <int PREC, int VARIANT>
+static int g2_launch(const Gemm2Args& a, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv2_kernel<PREC, VARIANT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess)
+      return OFX_ELAUNCH;
+    attr_set = true;
+  }
+  gconv2_kernel<PREC, VARIANT><<<a.e.ntm * a.e.ntn, 512, G2_LDS, st>>>(a);
+  return OFX_OK;
+}
+
+extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int cin, int64_t n_nodes,
+                                        const int32_t* seg_ptr, const int32_t* col, const int32_t* nbr_ext,
+                                        const int32_t* multi_seg, int64_t n_multi, void* aux, const void* tfp,
+                                        int64_t ldt_bytes, int nt, const void* W2, int cout, const float* bias,
+                                        const float* emb, int64_t lde, const int32_t* batch_id, const float* res,
+                                        int64_t ldr, float* out, int64_t ldc, double* stats, int64_t stats_ld, void* ws,
+                                        size_t ws_bytes, int mode, void* stream) {
+  if (mode != 1 && mode != 2) return OFX_EINVAL;
+  const int64_t ch = g2_chunk(mode);
+  if (n_nodes == 0 && cin >= 1 && cout >= 1) return OFX_OK;
+  if (n_nodes < 0 || cin < 1 || (cin % ch) || cout < 1 || !xp || !seg_ptr || !col || !nbr_ext || !aux || !W2 || !out ||
+      ldx_bytes < (int64_t)cin * (mode == 2 ? 4 : 2) || (ldx_bytes & 15) || ((uintptr_t)xp & 127) ||
+      ((uintptr_t)aux & 127) || ((uintptr_t)W2 & 127) || ldc < cout || (res && ldr < cout) ||
+      (emb && (!batch_id || lde < cout)) || n_multi < 0 || (n_multi > 0 && !multi_seg) || nt < 0)
+    return OFX_EINVAL;
+  const int ntc = nt > 1 ? nt : 0;
+  if (ntc > 0 && (!tfp || (ldt_bytes & 15) || ((uintptr_t)tfp & 127))) return OFX_EINVAL;
+  if (stats && (!batch_id || stats_ld < cout)) return OFX_EINVAL;
+  hipStream_t st = ofx_stream(stream);
+  planes_multi_mean_kernel<<<ofx_grid((n_multi + 1) * (cin / 8), 256), 256, 0, st>>>(
+      (const char*)xp, ldx_bytes, cin, seg_ptr, col, multi_seg, n_multi, mode, (char*)aux);
+  Gemm2Args a = {};
+  a.xp = (const char*)xp; a.ldx = ldx_bytes; a.aux = (const char*)aux; a.n_src = n_nodes; a.nbr_ext = nbr_ext;
+  a.tfp = ntc ? (const char*)tfp : (const char*)xp; a.ldt = ntc ? ldt_bytes : ldx_bytes;
+  a.W2 = (const char*)W2;
+  a.tpd = (int)(cin / ch); a.nkt_g = 7 * a.tpd; a.nkt = (int)ofx_planes_packed_ktiles(cin, nt, mode);
+  GemmArgs& g = a.e;
+  g.M = n_nodes; g.N = cout; g.K = g.Kp = (int64_t)a.nkt * ch; g.bias = bias; g.emb = emb; g.lde = lde; g.bid = batch_id;
+  g.res = res; g.ldr = ldr; g.out = out; g.ldc = ldc; g.nsplit = 1;
+  {
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    g.vec4 = g.N % 4 == 0 && al16(g.out) && g.ldc % 4 == 0 && (!g.res || (al16(g.res) && g.ldr % 4 == 0)) &&
+             (!g.emb || (al16(g.emb) && g.lde % 4 == 0)) && (!g.bias || al16(g.bias));
+  }
+  g.ntm = (int)ofx_cdiv(g.M, G2_BM);
+  g.ntn = (int)ofx_cdiv(g.N, G2_BN);
+  if (stats) {
+    g.stats = stats; g.stats_ld = stats_ld;
+    const int64_t nwr = ofx_cdiv(g.M, 64);
+    if (g.vec4 && ws && (size_t)nwr * g.N * 2 * sizeof(float) <= ws_bytes && (((uintptr_t)ws) & 15) == 0) {
+      g.stats_part = (float*)ws; g.stats_part_bytes = ws_bytes;
+    }
+  }
+  int rc;
+  if (mode == 2) rc = g2_variant ? g2_launch<2, 1>(a, st) : g2_launch<2, 0>(a, st);
+  else rc = g2_variant ? g2_launch<1, 1>(a, st) : g2_launch<1, 0>(a, st);
+  if (rc) return rc;
+  if (g.stats_part) {
+    rc = ofx_launch_stats_reduce(g, 64, st);
+    if (rc) return rc;
+  }
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}

@@ -172,6 +172,70 @@ extern "C" int ofx_gn_apply(const float* x, int64_t ldx, int64_t n, int C, const
   return OFX_OK;
 }
 
+// Same normalisation, but the result leaves as OPERAND PLANES for the LDS-DMA GraphConv (ofx_gemm2.hip):
+// mode 2: per 32-channel chunk one 128-B line [bf16 hi x 32 | bf16 lo x 32] (y = hi + lo to 2^-17) -- the bytes
+// of the fp32 row, so `out` may alias an fp32-shaped buffer, including x itself (lane q of an 8-lane group reads
+// channels 4q..4q+3 of the chunk and writes bytes 8q..8q+7 of each half: every load of the wave instruction has
+// returned before any of its stores issues); mode 1: fp16 row-major.
+__device__ __forceinline__ unsigned gn_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__global__ void __launch_bounds__(256) gn_apply_planes_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int C,
+                                                              const int32_t* __restrict__ bid,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, int act, int mode,
+                                                              char* __restrict__ out, int64_t ldo) {
+  const int CT = C >> 2;
+  const int64_t total = n * CT;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / CT;
+    const int c = (int)(t - r * CT) * 4;
+    const int b = bid[r];
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    const float4 m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c);
+    const float4 rs = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c);
+    const float4 ww = *reinterpret_cast<const float4*>(w + c);
+    const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+    const float ox = ofx_apply_act((v.x - m.x) * rs.x * ww.x + bb.x, act);
+    const float oy = ofx_apply_act((v.y - m.y) * rs.y * ww.y + bb.y, act);
+    const float oz = ofx_apply_act((v.z - m.z) * rs.z * ww.z + bb.z, act);
+    const float ow = ofx_apply_act((v.w - m.w) * rs.w * ww.w + bb.w, act);
+    if (mode == 2) {
+      const unsigned h0 = gn_pk_bf16(ox, oy), h1 = gn_pk_bf16(oz, ow);
+      const unsigned l0 = gn_pk_bf16(ox - __uint_as_float(h0 << 16), oy - __uint_as_float(h0 & 0xffff0000u));
+      const unsigned l1 = gn_pk_bf16(oz - __uint_as_float(h1 << 16), ow - __uint_as_float(h1 & 0xffff0000u));
+      char* o = out + r * ldo + (c >> 5) * 128 + (c & 31) * 2;
+      *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(o + 64) = make_uint2(l0, l1);
+    } else {
+      const _Float16 a0 = (_Float16)ox, a1 = (_Float16)oy, a2 = (_Float16)oz, a3 = (_Float16)ow;
+      uint2 o;
+      o.x = (unsigned)__builtin_bit_cast(unsigned short, a0) | ((unsigned)__builtin_bit_cast(unsigned short, a1) << 16);
+      o.y = (unsigned)__builtin_bit_cast(unsigned short, a2) | ((unsigned)__builtin_bit_cast(unsigned short, a3) << 16);
+      *reinterpret_cast<uint2*>(out + r * ldo + c * 2) = o;
+    }
+  }
+}
+
+extern "C" int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,
+                                   const float* mean, const float* rstd, const float* w, const float* bias, int act,
+                                   int mode, void* out, int64_t ldo_bytes, void* stream) {
+  const int chunk = mode == 2 ? 32 : 64;
+  if ((mode != 1 && mode != 2) || !x || !batch_id || !mean || !rstd || !w || !bias || !out || n < 0 || C < chunk ||
+      (C % chunk) || ldx < C || (ldx & 3) || ldo_bytes < (int64_t)C * (mode == 2 ? 4 : 2) || (ldo_bytes & 15) ||
+      ((uintptr_t)x & 15) || ((uintptr_t)out & 127) || ((uintptr_t)w & 15) || ((uintptr_t)bias & 15) ||
+      ((uintptr_t)mean & 15) || ((uintptr_t)rstd & 15) || act < 0 || act > 2)
+    return OFX_EINVAL;
+  if (n > 0)
+    gn_apply_planes_kernel<<<ofx_grid(n * (C / 4), 256), 256, 0, ofx_stream(stream)>>>(
+        x, ldx, n, C, batch_id, mean, rstd, w, bias, act, mode, (char*)out, ldo_bytes);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
 // elementwise activation (shared with ofx_misc entry point)
 __global__ void act_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int act) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)

@@ -221,6 +221,14 @@ class DualOctree:
             self._tf[key] = tf
         return self._tf[key]
 
+    def type_frac_planes(self, d, nt, mode):
+        """type_frac(d, nt) as operand planes of the LDS-DMA GraphConv (zero-padded to a whole chunk)."""
+        key = ('tfp', d, nt, mode)
+        if key not in self._tf:
+            from . import ops
+            self._tf[key] = ops.planes_split(self.type_frac(d, nt), mode)
+        return self._tf[key]
+
     def pad_rows(self, d):
         """int32 [N_d]: position of graph row r inside the node_mask-long padded array
         (graph_vae.py:214-221: `pad[node_mask] = reg`)."""

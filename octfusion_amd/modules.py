@@ -48,7 +48,21 @@ class GraphConv(nn.Module):
             self.bias = nn.Parameter(torch.empty(out_channels))
         self.reset_parameters()
         self._pw = ops.PackedWeight()
+        self._pw2 = ops.PackedPlanes()
         self.emit_stats = True
+
+    def planes_mode(self, doctree, d):
+        """Operand-plane format this layer wants its input in (0: plain fp32 rows): the LDS-DMA kernel takes the
+        layers with enough 256 x 128 tiles and whole 32 (64)-channel chunks."""
+        mode = ops.planes_mode()
+        if not mode:
+            return 0
+        N = doctree.csr(d)[2]
+        tiles = ((N + 255) // 256) * ((self.out_channels + 127) // 128)
+        if (self.in_channels % (32 if mode == 2 else 64) or self.out_channels % 4 or self.out_channels < 64 or
+                tiles < ops.PLANES_MIN_TILES):
+            return 0
+        return mode
 
     def reset_parameters(self):
         fan_in = self.avg_degree * self.in_channels
@@ -59,18 +73,35 @@ class GraphConv(nn.Module):
             nn.init.zeros_(self.bias)
 
     @torch.no_grad()
-    def forward(self, x, doctree, d, emb=None, res=None, out=None):
+    def forward(self, x, doctree, d, emb=None, res=None, out=None, split_input=False):
         """``emb`` [B, Cout] (added per batch element) and ``res`` [N, Cout] are optional
-        fused epilogue terms (the reference adds them with separate ops)."""
+        fused epilogue terms (the reference adds them with separate ops).  ``x`` may be operand planes
+        (written by the preceding GroupNorm); ``split_input``: convert an fp32 ``x`` when this layer
+        qualifies for the planes kernel."""
         nt = self.n_node_type if self.n_node_type > 1 else 0
-        pw = self._pw.get(self.weights, 'graphconv', self.in_channels, nt)
         seg_ptr, col, N, E = doctree.csr(d)
         assert x.shape[0] == N, 'x has %d rows, graph depth %d has %d nodes' % (x.shape[0], d, N)
-        tf = doctree.type_frac(d, nt) if nt else None
         # large outputs feed a DualOctreeGroupNorm next: let the epilogue accumulate its statistics
         stats = None
         if self.emit_stats and N * self.out_channels >= (1 << 20) and self.out_channels % 4 == 0:
             stats = ops.stats_zeros(doctree.batch_size * self.out_channels * 2, x.device)
+        mode = ops.planes_of(x)
+        if not mode and split_input:
+            mode = self.planes_mode(doctree, d)
+            if mode:
+                x = ops.planes_split(x, mode)
+        if mode:
+            pw2 = self._pw2.get(self.weights, self.in_channels, nt, mode)
+            y = ops.graphconv_planes(x, mode, seg_ptr, col, doctree.ext(d), pw2, self.in_channels, nt,
+                                     doctree.type_frac_planes(d, nt, mode) if nt else None,
+                                     self.bias if self.use_bias else None, emb,
+                                     doctree.batch_id32(d) if (emb is not None or stats is not None) else None,
+                                     res, out, stats=stats)
+            if stats is not None:
+                setattr(y, ops.STATS_ATTR, stats)
+            return y
+        pw = self._pw.get(self.weights, 'graphconv', self.in_channels, nt)
+        tf = doctree.type_frac(d, nt) if nt else None
         y = ops.graphconv(x, doctree.nbr(d), seg_ptr, col, pw, self.in_channels, tf,
                           self.bias if self.use_bias else None, emb,
                           doctree.batch_id32(d) if (emb is not None or stats is not None) else None, res, out,
@@ -98,11 +129,14 @@ class DualOctreeGroupNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, in_channels))
 
     @torch.no_grad()
-    def forward(self, data, doctree, depth, act=None, out=None):
+    def forward(self, data, doctree, depth, act=None, out=None, planes=0):
+        """``planes``: write the result as operand planes of the LDS-DMA GraphConv (ops.planes_mode())."""
         assert doctree.batch_id32(depth).shape[0] == data.shape[0]
         stats = ops.get_stats(data)
+        if planes == 2 and out is not None and not ops.planes_ok(out, 2):
+            out = None
         y = ops.group_norm(data, doctree.batch_id32(depth), doctree.count(depth), doctree.batch_size,
-                           self.weights, self.bias, self.group, self.eps, act, out, stats=stats)
+                           self.weights, self.bias, self.group, self.eps, act, out, stats=stats, planes=planes)
         if out is data and stats is not None:
             delattr(data, ops.STATS_ATTR)          # overwritten in place: the sums no longer describe it
         return y
@@ -253,7 +287,7 @@ class GraphDownsample(nn.Module):
         self.conv = GraphConv(channels_in, channels_out, n_edge_type, avg_degree, n_node_type)
 
     def forward(self, x, doctree, d, out=None):
-        return self.conv(pool_nodes(x, doctree, d, self.downsample), doctree, d - 1, out=out)
+        return self.conv(pool_nodes(x, doctree, d, self.downsample), doctree, d - 1, out=out, split_input=True)
 
 
 class GraphUpsample(nn.Module):
@@ -267,7 +301,7 @@ class GraphUpsample(nn.Module):
         self.conv = GraphConv(channels_in, channels_out, n_edge_type, avg_degree, n_node_type)
 
     def forward(self, x, doctree, d, out=None):
-        return self.conv(unpool_nodes(x, doctree, d, self.upsample), doctree, d + 1, out=out)
+        return self.conv(unpool_nodes(x, doctree, d, self.upsample), doctree, d + 1, out=out, split_input=True)
 
 
 def graphnormalization(channels):
@@ -310,13 +344,13 @@ class GraphResBlockEmbed(TimestepBlock):
     def forward(self, x, emb, doctree, depth, emb_act=None, out=None):
         """``emb_act``: optional precomputed SiLU(emb) shared by all blocks of a step; ``out``: optional
         destination (may be a column slice of a wider buffer: zero-copy skip concatenation)."""
-        h = self.block1_norm(x, doctree, depth, act='silu')
+        h = self.block1_norm(x, doctree, depth, act='silu', planes=self.conv1.planes_mode(doctree, depth))
         if emb_act is None:
             emb_act = ops.act(emb, 'silu')
         emb_out = self.emb_layers[1](emb_act)                       # [B, Cout]
         assert doctree.batch_size == emb_out.shape[0]
         h = self.conv1(h, doctree, depth, emb=emb_out)              # + emb_out[batch_id] fused
-        h = self.block2_norm(h, doctree, depth, act='silu', out=h)
+        h = self.block2_norm(h, doctree, depth, act='silu', out=h, planes=self.conv2.planes_mode(doctree, depth))
         skip = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x)
         return self.conv2(h, doctree, depth, res=skip, out=out)     # skip + h fused
 
@@ -340,9 +374,9 @@ class GraphResBlock(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, doctree, depth):
-        h = self.norm1(x, doctree, depth, act='silu')
+        h = self.norm1(x, doctree, depth, act='silu', planes=self.conv1.planes_mode(doctree, depth))
         h = self.conv1(h, doctree, depth)
-        h = self.norm2(h, doctree, depth, act='silu', out=h)
+        h = self.norm2(h, doctree, depth, act='silu', out=h, planes=self.conv2.planes_mode(doctree, depth))
         if self.channel_in != self.channel_out:
             x = self.conv1x1c(x, doctree, depth)
         return self.conv2(h, doctree, depth, res=x)

@@ -43,9 +43,150 @@ def _row_major(t):
 _WS = {}
 
 
+PRECISIONS = {'bf16x3': 0, 'fp32': 1, 'fp16': 2}
+
+
 def set_precision(mode):
-    """'bf16x3' (default: fp32-class accuracy on the bf16 matrix pipe) or 'fp32' (exact fp32 MFMA)."""
-    call('ofx_set_precision', {'bf16x3': 0, 'fp32': 1}[mode])
+    """'bf16x3' (default: fp32-class accuracy on the bf16 matrix pipe), 'fp32' (exact fp32 MFMA) or
+    'fp16' (reduced precision: single-pass fp16 MFMA in the planes GraphConv, everything else bf16x3)."""
+    call('ofx_set_precision', PRECISIONS[mode])
+
+
+def get_precision():
+    code = _lib.lib().ofx_get_precision()
+    return [k for k, v in PRECISIONS.items() if v == code][0]
+
+
+# ---- operand planes (csrc/ofx_gemm2.hip): the LDS-DMA GraphConv and its producers --------------------
+PLANES_ATTR = '_ofx_planes'
+USE_PLANES = True            # A/B switch: False keeps every GraphConv on the register-staged kernel
+PLANES_MIN_TILES = 128       # 256 x 128 tiles; below this the old kernel (128 x 128 tiles, split-K) fills the chip better
+
+
+def planes_mode():
+    """0: off, 2: bf16x3 planes, 1: fp16 planes -- follows the contraction precision."""
+    if not USE_PLANES:
+        return 0
+    code = _lib.lib().ofx_get_precision()
+    return {0: 2, 1: 0, 2: 1}[code]
+
+
+def planes_of(t):
+    return getattr(t, PLANES_ATTR, 0)
+
+
+def _planes_chunk(mode):
+    return 32 if mode == 2 else 64
+
+
+def _planes_out(n, C, mode, device, out=None):
+    """(tensor, row pitch in bytes) for a planes tensor of n rows x C channels."""
+    if mode == 2:
+        if out is None:
+            out = torch.empty(n, C, dtype=torch.float32, device=device)
+        assert out.dtype == torch.float32 and out.shape == (n, C) and out.stride(1) == 1
+        ld = out.stride(0) * 4 if n > 1 else C * 4
+    else:
+        out = torch.empty(n, C, dtype=torch.float16, device=device)
+        ld = C * 2
+    assert out.data_ptr() % 128 == 0 and ld % 128 == 0, 'planes need 128-B aligned rows'
+    return out, ld
+
+
+def planes_ok(t, mode):
+    """can tensor `t` (fp32 [n, C]) be overwritten in place by its mode-2 planes?"""
+    return (mode == 2 and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and
+            t.data_ptr() % 128 == 0 and (t.stride(0) * 4) % 128 == 0 and t.shape[1] % 32 == 0)
+
+
+def planes_split(x, mode, Cpad=None, out=None):
+    """fp32 [n, C] -> planes (C zero-padded to Cpad)."""
+    x, ldx = _row_major(x)
+    n, C = x.shape
+    ch = _planes_chunk(mode)
+    Cpad = Cpad if Cpad is not None else (C + ch - 1) // ch * ch
+    out, ldo = _planes_out(n, Cpad, mode, x.device, out)
+    call('ofx_planes_split', ptr(x), ldx, n, C, Cpad, mode, ptr(out), ldo, stream())
+    setattr(out, PLANES_ATTR, mode)
+    return out
+
+
+def planes_merge(p, mode=None):
+    """planes -> fp32 [n, C] (tests)."""
+    mode = mode or planes_of(p)
+    n, C = p.shape
+    ld = p.stride(0) * (4 if mode == 2 else 2)
+    out = torch.empty(n, C, dtype=torch.float32, device=p.device)
+    call('ofx_planes_merge', ptr(p), ld, n, C, mode, ptr(out), C, stream())
+    return out
+
+
+class PackedPlanes:
+    """GraphConv weights packed as [k tile][cout][128-B line] for the planes kernel."""
+
+    def __init__(self):
+        self.t = None
+        self.key = None
+
+    def get(self, w, cin, nt, mode):
+        key = (w.data_ptr(), w._version, tuple(w.shape), cin, nt, mode)
+        if key == self.key:
+            return self
+        _chk(w)
+        w = w.detach()
+        if not w.is_contiguous():
+            w = w.contiguous()
+        K, N = w.shape
+        assert K == 7 * (cin + (nt if nt > 1 else 0))
+        L = _lib.lib()
+        out = torch.empty(L.ofx_planes_packed_bytes(cin, nt, N, mode), dtype=torch.uint8, device=w.device)
+        call('ofx_pack_weights_planes', ptr(w), N, 1, cin, nt, N, mode, ptr(out), stream())
+        self.t, self.key, self.N, self.K, self.cin, self.nt = out, key, N, K, cin, nt
+        self.nkt = L.ofx_planes_packed_ktiles(cin, nt, mode)
+        return self
+
+
+def graphconv_planes(xp, mode, seg_ptr, col, ext, pw, cin, nt, tf_planes=None, bias=None, emb=None, batch_id=None,
+                     res=None, out=None, stats=None):
+    """Fused GraphConv on operand planes (ofx_graphconv_fwd_planes)."""
+    assert planes_of(xp) == mode and xp.shape[1] == cin
+    N = xp.shape[0]
+    ldx = xp.stride(0) * (4 if mode == 2 else 2) if N > 1 else cin * (4 if mode == 2 else 2)
+    if out is None:
+        out = torch.empty(N, pw.N, dtype=torch.float32, device=xp.device)
+    out2, ldc = _row_major(out)
+    assert out2 is out
+    nbr_ext, multi_seg, n_multi = ext
+    aux = torch.empty((n_multi + 1) * ldx, dtype=torch.uint8, device=xp.device)
+    lde = ldr = ldt = 0
+    if emb is not None:
+        emb, lde = _row_major(emb)
+    if emb is not None or stats is not None:
+        _chk(batch_id, torch.int32)
+    if res is not None:
+        res, ldr = _row_major(res)
+    if tf_planes is not None:
+        ldt = tf_planes.stride(0) * (4 if mode == 2 else 2)
+    _chk(bias)
+    _chk(stats, torch.float64)
+    prof = GRAPHCONV_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    ws = workspace(xp.device)
+    call('ofx_graphconv_fwd_planes', ptr(xp), ldx, cin, N, ptr(seg_ptr), ptr(col), ptr(nbr_ext), ptr(multi_seg),
+         n_multi, ptr(aux), ptr(tf_planes), ldt, nt, ptr(pw.t), pw.N, ptr(bias), ptr(emb), lde,
+         ptr(batch_id) if (emb is not None or stats is not None) else None, ptr(res), ldr, ptr(out), ldc,
+         ptr(stats), pw.N, ptr(ws), ws.numel(), mode, stream())
+    if prof is not None:
+        e1.record()
+        E = col.numel()
+        s_in = 4.0 if mode == 2 else 2.0
+        flops = 2.0 * N * pw.K * pw.N
+        nbytes = s_in * (E * cin + pw.K * pw.N) + 4.0 * N * pw.N + 8.0 * E
+        prof.append((e0, e1, flops, nbytes, pw.N, ('graph2' if mode == 2 else 'graph2h', N, cin, pw.N)))
+    return out
 
 
 def workspace(device, nbytes=64 << 20):
@@ -380,7 +521,7 @@ def gather_mean(x, seg_ptr, col):
 
 
 def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, act=None, out=None,
-               count_eps=None, stats=None, rows_per_batch=None):
+               count_eps=None, stats=None, rows_per_batch=None, planes=0):
     """DualOctreeGroupNorm (+ optional fused activation).  count_eps=0 gives torch.nn.GroupNorm.
     stats: fp64 [B, C, 2] sums already produced by the epilogue of the kernel that wrote x.
     rows_per_batch: every batch element owns that many CONTIGUOUS rows (dense grids) -> one fused launch."""
@@ -389,7 +530,7 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
     x, ldx = _row_major(x)
     n, C = x.shape
     dev = x.device
-    if rows_per_batch is not None and stats is None and rows_per_batch * (C // groups) <= (1 << 16):
+    if rows_per_batch is not None and stats is None and not planes and rows_per_batch * (C // groups) <= (1 << 16):
         assert n == rows_per_batch * batch_size
         if out is None:
             out = torch.empty(n, C, dtype=torch.float32, device=dev)
@@ -409,12 +550,19 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         call('ofx_gn_stats', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
     call('ofx_gn_finalize', ptr(sums), ptr(count), batch_size, C, groups, eps, count_eps, ptr(mean), ptr(rstd),
          stream())
+    w = weight.detach().reshape(-1)
+    b = bias.detach().reshape(-1)
+    if planes:
+        # the consumer is the planes GraphConv: write its operand format directly (mode 2 may alias x)
+        out, ldo = _planes_out(n, C, planes, dev, out if planes == 2 else None)
+        call('ofx_gn_apply_planes', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(w), ptr(b),
+             ACT[act], planes, ptr(out), ldo, stream())
+        setattr(out, PLANES_ATTR, planes)
+        return out
     if out is None:
         out = torch.empty(n, C, dtype=torch.float32, device=dev)
     out2, ldo = _row_major(out)
     assert out2 is out
-    w = weight.detach().reshape(-1)
-    b = bias.detach().reshape(-1)
     call('ofx_gn_apply', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(w), ptr(b),
          ACT[act], ptr(out), ldo, stream())
     return out

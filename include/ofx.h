@@ -325,6 +325,10 @@ int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int cin, int64_t
                              int64_t stats_ld, void* ws, size_t ws_bytes, int mode, void* stream);
 /* scheduling variant of the planes kernel (0: DMA requests before the MFMA group, 1: interleaved) -- A/B knob */
 int ofx_set_gconv2_variant(int v);
+/* profiling aid: when buf != NULL every block of the following ofx_graphconv_fwd_planes launches writes 8 uint64
+ * to buf[block*8..]: shader-clock stamps at start / table built / first tile landed / k-loop done / stores drained,
+ * then HW_ID.  buf must hold 8 * (tiles of the largest launch) uint64.  NULL switches it off. */
+int ofx_set_gconv2_debug(void* buf);
 
 /* ---------------------------------------------------------------- dense grids
  * The nested dense U-Net (graph_unet_lr.py) in node-row layout: a full octree layer of

@@ -92,6 +92,7 @@ _SIGS = {
     'ofx_graphconv_fwd_planes': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_i,
                                        c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_sz, c_i, c_p], True),
     'ofx_set_gconv2_variant': (c_i, [c_i], True),
+    'ofx_set_gconv2_debug': (c_i, [c_p], True),
     'ofx_graph_multi_flag': (c_i, [c_p, c_l, c_p, c_p], True),
     'ofx_graph_primary_ext': (c_i, [c_p, c_p, c_l, c_p, c_p, c_p, c_p], True),
     'ofx_graph_primary': (c_i, [c_p, c_p, c_l, c_p, c_p], True),

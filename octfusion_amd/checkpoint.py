@@ -1,7 +1,9 @@
 """On-disk formats of the reference, read and written without the reference.
 
-* diffusion checkpoints `df_<label>.pth` (models/octfusion_model_union.py:501-545):
-  {'df_unet_lr', 'ema_df_unet_lr', ['df_unet_hr', 'ema_df_unet_hr'], 'opt', 'global_step'};
+* diffusion checkpoints `df_<label>.pth` (models/octfusion_model_union.py:501-545; 3-stage:
+  models/octfusion_model_union_3t.py:219-229 save, :250-261 load):
+  {'df_unet_lr', 'ema_df_unet_lr', ['df_unet_hr', 'ema_df_unet_hr'], ['df_unet_feature', 'ema_df_unet_feature'],
+   'opt', 'global_step'};
 * VAE checkpoints (models/model_utils.py:18-28): a state_dict, or {'autoencoder': sd}, or a
   '.solver.tar' file holding {'model_dict': sd};
 * sample files written by tools/gen_split.py:46-54 and read by datasets/dualoctree_snet.py:137-151:
@@ -20,25 +22,34 @@ def _read(ckpt):
     return ckpt
 
 
-def load_ckpt(ckpt, df, ema_df=None, load_options=('unet_lr', 'unet_hr')):
-    """octfusion_model_union.py:525-545 without the optimizer branch.  df / ema_df: union UNet3DModel
-    instances (ema_df may be None or df itself at inference).  Returns the checkpoint's global_step."""
+STAGE_NETS = ('unet_lr', 'unet_hr', 'unet_feature')
+_STAGES_UP_TO = {'lr': 1, 'hr': 2, 'feature': 3}
+
+
+def load_ckpt(ckpt, df, ema_df=None, load_options=STAGE_NETS, opt=None):
+    """octfusion_model_union.py:525-545 / octfusion_model_union_3t.py:250-261.  df / ema_df: union UNet3DModel
+    instances (ema_df may be None or df itself at inference); every stage net present in BOTH the file and `df` and
+    named in load_options is loaded strictly.  opt: optional training.AdamW whose state is restored from 'opt' when
+    the file holds one written by save_ckpt (a torch.optim state from the reference is keyed by parameter index and
+    is not convertible without the reference's parameter order: ignored).  Returns the checkpoint's global_step."""
     sd = _read(ckpt)
-    for name in ('unet_lr', 'unet_hr'):
-        if name in load_options and 'df_' + name in sd:
+    for name in STAGE_NETS:
+        if name in load_options and 'df_' + name in sd and getattr(df, name, None) is not None:
             getattr(df, name).load_state_dict(sd['df_' + name], strict=True)
-            if ema_df is not None:
+            if ema_df is not None and getattr(ema_df, name, None) is not None:
                 getattr(ema_df, name).load_state_dict(sd['ema_df_' + name], strict=True)
+    if opt is not None and isinstance(sd.get('opt'), dict) and 'state' in sd['opt'] and 'param_groups' not in sd['opt']:
+        opt.load_state_dict(sd['opt'])
     return sd.get('global_step')
 
 
 def save_ckpt(path, df, ema_df, global_step, stage_flag='hr', opt_state=None):
-    """octfusion_model_union.py:501-523 (file layout only; rotation of old files is the trainer's business)."""
-    sd = {'df_unet_lr': df.unet_lr.state_dict(), 'ema_df_unet_lr': ema_df.unet_lr.state_dict(),
-          'opt': opt_state if opt_state is not None else {}, 'global_step': global_step}
-    if stage_flag == 'hr':
-        sd['df_unet_hr'] = df.unet_hr.state_dict()
-        sd['ema_df_unet_hr'] = ema_df.unet_hr.state_dict()
+    """octfusion_model_union.py:501-523 / octfusion_model_union_3t.py:219-229 (file layout only; rotation of old
+    files is the trainer's business): the nets of every stage up to `stage_flag`."""
+    sd = {'opt': opt_state if opt_state is not None else {}, 'global_step': global_step}
+    for name in STAGE_NETS[:_STAGES_UP_TO[stage_flag]]:
+        sd['df_' + name] = getattr(df, name).state_dict()
+        sd['ema_df_' + name] = getattr(ema_df, name).state_dict()
     torch.save(sd, path)
 
 

@@ -25,6 +25,8 @@
 // accumulate: same arithmetic as ofx_gemm.hip's default), PREC 1 = one v_mfma_f32_32x32x16_f16 per product
 // (operands rounded to fp16: ~5e-4 per product, reduced-precision mode for BASELINE configs[4]).
 // The epilogue (bias / time-embedding / residual / fused GroupNorm statistics) is shared with ofx_gemm.hip.
+#include <type_traits>
+
 #include "ofx_gemm_common.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -51,8 +53,15 @@ struct Gemm2Args {
   const char* tfp; int64_t ldt;           // node-type slab planes (row pitch bytes) or the activation planes again
   const char* W2;                         // [nkt][N][128 B]
   int tpd, nkt_g, nkt;                    // k tiles per direction, gather tiles (7 * tpd), all tiles
+  unsigned long long* dbg;                // optional [blocks][8] shader-clock stamps (ofx_set_gconv2_debug)
   GemmArgs e;                             // M, N, epilogue operands, tile grid
 };
+
+__device__ __forceinline__ unsigned long long g2_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+  return t;
+}
 
 template <int PREC> struct G2Frag;
 template <> struct G2Frag<2> { typedef bf16x8_t T; };
@@ -107,6 +116,170 @@ __device__ __forceinline__ void g2_wait_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
 }
 
+// ---- two-phase epilogue.  With ONE block per CU nothing else hides the latency of the epilogue's own loads: the
+// shared epilogue (ofx_gemm_common.h) loads a residual piece, waits for it, stores, 16 times over -- measured at
+// 51 k shader clocks per block against 57 k for the whole 30-step k-loop (tools/gconv2_timeline.py).  Here every
+// operand the epilogue needs (residual rows, bias, time-embedding rows, batch ids) is REQUESTED before the last
+// two k-steps and consumed after them.  Same lane -> element mapping as epilogue_store_v4: lane (k = l31 >> 2,
+// q = l31 & 3, h) owns rows q + 4h + 8G + 32i (G < 4, i < MI) of its wave's 32 MI rows, columns 4k..4k+3 of every
+// 32-column group j.
+typedef float g2_v4f __attribute__((ext_vector_type(4)));
+template <int MI, int NI>
+struct G2Epi {
+  g2_v4f res[MI][NI][4];
+  g2_v4f bias[NI];
+  int bids[MI][4];
+};
+constexpr int G2_EPI_LOADS = G2_MI * G2_NI * 4 + G2_NI + G2_MI * 4;      // 26 VMEM loads, always
+
+// The requests are inline asm: their NUMBER enters a counted s_waitcnt vmcnt(N) of the k-loop (the DMA of the next
+// tile must be waited for without waiting for these), so the compiler must neither merge, drop nor reorder them.
+// Absent operands (no residual / bias / batch ids) read a dummy line of the packed weights instead.
+__device__ __forceinline__ void g2_req128(g2_v4f& d, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p));
+}
+__device__ __forceinline__ void g2_req32(int& d, const void* p) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p));
+}
+
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void g2_epilogue_request(const GemmArgs& g, const void* dummy, G2Epi<MI, NI>& P, int64_t m0,
+                                                    int64_t n0, int wm, int wn, int l31, int h) {
+  const int q = l31 & 3, k = l31 >> 2;
+  const int64_t mw = m0 + wm * MI * 32;
+  const int64_t mlast = g.M - 1;
+  const bool need_bid = g.emb || g.stats;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+      int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
+      m = m < mlast ? m : mlast;
+      g2_req32(P.bids[i][G], need_bid ? (const void*)(g.bid + m) : dummy);
+    }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
+    n = n < g.N ? n : g.N - 4;                               // clamped: out-of-range columns are never stored
+    g2_req128(P.bias[j], g.bias ? (const void*)(g.bias + n) : dummy);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {
+        int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
+        m = m < mlast ? m : mlast;
+        g2_req128(P.res[i][j][G], g.res ? (const void*)(g.res + m * g.ldr + n) : dummy);
+      }
+  }
+}
+// after the vmcnt(0) of the last k-steps: ties every requested register to this point of the instruction stream
+template <int MI, int NI>
+__device__ __forceinline__ void g2_epilogue_landed(G2Epi<MI, NI>& P) {
+  static_assert(MI == 2 && NI == 2, "operand list written for the 64 x 64 wave tile");
+  asm volatile("" : "+v"(P.res[0][0][0]), "+v"(P.res[0][0][1]), "+v"(P.res[0][0][2]), "+v"(P.res[0][0][3]),
+                    "+v"(P.res[0][1][0]), "+v"(P.res[0][1][1]), "+v"(P.res[0][1][2]), "+v"(P.res[0][1][3]),
+                    "+v"(P.res[1][0][0]), "+v"(P.res[1][0][1]), "+v"(P.res[1][0][2]), "+v"(P.res[1][0][3]),
+                    "+v"(P.res[1][1][0]), "+v"(P.res[1][1][1]), "+v"(P.res[1][1][2]), "+v"(P.res[1][1][3]),
+                    "+v"(P.bias[0]), "+v"(P.bias[1]));
+  asm volatile("" : "+v"(P.bids[0][0]), "+v"(P.bids[0][1]), "+v"(P.bids[0][2]), "+v"(P.bids[0][3]),
+                    "+v"(P.bids[1][0]), "+v"(P.bids[1][1]), "+v"(P.bids[1][2]), "+v"(P.bids[1][3]));
+}
+
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&acc)[MI][NI], G2Epi<MI, NI>& P, int64_t m0,
+                                                   int64_t n0, int wm, int wn, int l31, int h) {
+  const int q = l31 & 3, k = l31 >> 2;
+  const bool q0 = q & 1, q1 = q & 2;
+  const int64_t mw = m0 + wm * MI * 32;
+  const int64_t tile_m = m0 / (WM * MI * 32);
+  bool uni = true;
+  int b0 = 0;
+  if (g.emb || g.stats) {
+    // batch id of the wave's first row = lane 0's first row (reading it here, not in the request phase, keeps a
+    // scalarised load + wait out of the k-loop's tail)
+    b0 = __builtin_amdgcn_readfirstlane(P.bids[0][0]);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int G = 0; G < 4; ++G) uni = uni && (P.bids[i][G] == b0);
+    uni = __all(uni);
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
+    const bool ncol = n < g.N;
+    const int64_t nc = ncol ? n : g.N - 4;
+    float4 eu = f4zero();
+    if (g.emb && uni) eu = *reinterpret_cast<const float4*>(g.emb + (int64_t)b0 * g.lde + nc);
+    const float4 bv = g.bias ? make_float4(P.bias[j].x, P.bias[j].y, P.bias[j].z, P.bias[j].w) : f4zero();
+    float4 ssum = f4zero(), ssq = f4zero();
+    int sb = -1;
+    auto flush = [&](int b) {
+      double* o = g.stats + ((int64_t)b * g.stats_ld + n) * 2;
+      unsafeAtomicAdd(o + 0, (double)ssum.x); unsafeAtomicAdd(o + 1, (double)ssq.x);
+      unsafeAtomicAdd(o + 2, (double)ssum.y); unsafeAtomicAdd(o + 3, (double)ssq.y);
+      unsafeAtomicAdd(o + 4, (double)ssum.z); unsafeAtomicAdd(o + 5, (double)ssq.z);
+      unsafeAtomicAdd(o + 6, (double)ssum.w); unsafeAtomicAdd(o + 7, (double)ssq.w);
+    };
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float4 t[4];
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {                         // every lane takes part in the transposes
+        float v0 = acc[i][j][4 * G], v1 = acc[i][j][4 * G + 1], v2 = acc[i][j][4 * G + 2], v3 = acc[i][j][4 * G + 3];
+        quad_transpose(v0, v1, v2, v3, q0, q1);
+        t[G] = make_float4(v0 + bv.x, v1 + bv.y, v2 + bv.z, v3 + bv.w);
+      }
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {
+        const int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
+        if (m >= g.M || !ncol) continue;
+        float4 v = t[G];
+        if (g.emb) {
+          if (uni) f4add(v, eu);
+          else f4add(v, *reinterpret_cast<const float4*>(g.emb + (int64_t)P.bids[i][G] * g.lde + n));
+        }
+        if (g.res) f4add(v, make_float4(P.res[i][j][G].x, P.res[i][j][G].y, P.res[i][j][G].z, P.res[i][j][G].w));
+        if (g.stats) {
+          const int b = P.bids[i][G];
+          if (!uni && b != sb) {
+            if (sb >= 0) flush(sb);
+            ssum = f4zero(); ssq = f4zero();
+          }
+          sb = b;
+          f4add(ssum, v);
+          ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
+        }
+        *reinterpret_cast<float4*>(g.out + m * g.ldc + n) = v;
+      }
+    }
+    if (g.stats) {
+      if (uni) {
+#define OFX_RED(f) f += dpp_xor1(f); f += dpp_xor2(f); f += __shfl_xor(f, 32);
+        OFX_RED(ssum.x) OFX_RED(ssum.y) OFX_RED(ssum.z) OFX_RED(ssum.w)
+        OFX_RED(ssq.x) OFX_RED(ssq.y) OFX_RED(ssq.z) OFX_RED(ssq.w)
+#undef OFX_RED
+        if (q == 0 && h == 0 && ncol && mw < g.M) {
+          if (g.stats_part) {
+            float* o = g.stats_part + ((tile_m * WM + wm) * g.N + n) * 2;
+            *reinterpret_cast<float4*>(o) = make_float4(ssum.x, ssq.x, ssum.y, ssq.y);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(ssum.z, ssq.z, ssum.w, ssq.w);
+          } else {
+            flush(b0);
+          }
+        }
+      } else {
+        if (sb >= 0 && ncol) flush(sb);
+        if (g.stats_part && q == 0 && h == 0 && ncol && mw < g.M) {      // mixed wave: its slot must read as zero
+          float* o = g.stats_part + ((tile_m * WM + wm) * g.N + n) * 2;
+          *reinterpret_cast<float4*>(o) = f4zero();
+          *reinterpret_cast<float4*>(o + 4) = f4zero();
+        }
+      }
+    }
+  }
+}
+
 constexpr int G2_GLDS_PER_STEP = 6;                   // DMA instructions per wave per k-step (4 A + 2 B)
 
 template <int PREC, int VARIANT>
@@ -128,6 +301,9 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, h = lane >> 5;
+  const bool dbg = a.dbg != nullptr;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+  if (dbg) ts0 = g2_clock();
 
   // ---- neighbour-table slice of this row tile -> LDS, already translated to unsigned 128-B LINE offsets:
   //   tab[r][d < 7] = line offset of source row nbr_ext[m, d] from xlo = min(xp, aux) (rows >= n_src live in `aux`),
@@ -156,6 +332,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
     }
   }
   __syncthreads();
+  if (dbg) ts1 = g2_clock();
 
   // ---- wave-uniform loop operands pinned in SGPRs
   auto sgpr32 = [](int v) {
@@ -306,6 +483,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
   } else {
     g2_wait_barrier<0>();
   }
+  if (dbg) ts2 = g2_clock();
   read_half(0, 0, F0);
 
   // One k-step.  On entry: F0 = first half of tile `it` (8 reads, possibly still in flight), tile it+1 requested.
@@ -314,11 +492,20 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
   //   wait (tile it+1 landed, all own LDS reads done) + barrier | 8 reads: first half of tile it+1 -> F0 | MFMAs of F1
   // ob / obn / obnn: byte offsets of the stage buffers of tiles it, it+1, it+2 (rotating).
   int ob = 0, obn = G2_BUF, obnn = 2 * G2_BUF;
-  auto step_issue = [&](const Tile& T) {
+  // `last`: the final steady-state step also REQUESTS the epilogue's operands (26 loads, issued before its DMA) so
+  // that they travel during the last ~2.5 k-steps; its barrier lets those 26 + the 6 new DMA stay outstanding.
+  G2Epi<G2_MI, G2_NI> P;
+  const bool vec4 = g.vec4 != 0;
+  auto step_issue = [&](const Tile& T, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
     load_idx(T, I);
     read_half(ob, 1, F1);
     g2_wait_lgkm<12, PREC>(F0);
     G2_FENCE();
+    if (LAST) {
+      g2_epilogue_request<G2_WM, G2_WN, G2_MI, G2_NI>(g, (const void*)a.W2, P, m0, n0, wm, wn, l31, h);
+      G2_FENCE();
+    }
     g2_wait_lgkm<8>(I);
     issue(T, obnn, I);
     if (VARIANT == 0) {
@@ -335,7 +522,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
       }
     }
     G2_FENCE();
-    g2_wait_barrier<G2_GLDS_PER_STEP, PREC>(F1);
+    g2_wait_barrier<G2_GLDS_PER_STEP + (LAST ? G2_EPI_LOADS : 0), PREC>(F1);
     G2_FENCE();
     read_half(obn, 0, F0);
     G2_FENCE();
@@ -343,22 +530,24 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
     G2_FENCE();
     const int t = ob; ob = obn; obn = obnn; obnn = t;
   };
-  int it = 0;
-  {   // steady state, gather tiles: tile it+2 = (chunk gc, direction gd), advanced without division
-    int gd = 2, gc = 0;                                          // nkt_g >= 7 > 2
-    for (; it + 2 < nkt_g; ++it) {
-      Tile T;
-      T.tcol = gd; T.ktw = gd * tpd + gc; T.base = xp_s + (int64_t)gc * G2_LINE;
-      step_issue(T);
-      const int wrap = gd == 6;
-      gd = wrap ? 0 : gd + 1;
-      gc += wrap;
-    }
-  }
-  for (; it + 2 < nkt; ++it) {                                   // steady state, node-type tiles
+  // tile it+2 of the k order = (chunk gc, direction gd) while it is a gather tile, advanced without division
+  int it = 0, gd = 2, gc = 0;                                      // nkt_g >= 7 > 2
+  auto next_tile = [&]() {
+    const int ti = it + 2;
+    const bool gat = ti < nkt_g;
     Tile T;
-    T.tcol = 7; T.ktw = it + 2; T.base = tfp_s + (int64_t)(it + 2 - nkt_g) * G2_LINE;
-    step_issue(T);
+    T.tcol = gat ? gd : 7;
+    T.ktw = gat ? gd * tpd + gc : ti;
+    T.base = (gat ? xp_s : tfp_s) + (int64_t)(gat ? gc : ti - nkt_g) * G2_LINE;
+    const int wrap = gd == 6;
+    gd = wrap ? 0 : gd + 1;
+    gc += wrap;
+    return T;
+  };
+  for (; it + 3 < nkt; ++it) step_issue(next_tile(), std::false_type());
+  if (it + 2 < nkt) {                            // always taken: nkt >= 7 (host-checked)
+    step_issue(next_tile(), std::true_type());
+    ++it;
   }
   for (; it < nkt; ++it) {                       // last two tiles: nothing left to request
     read_half(ob, 1, F1);
@@ -374,9 +563,21 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
     G2_FENCE();
     const int t = ob; ob = obn; obn = obnn; obnn = t;
   }
+  g2_epilogue_landed(P);
 #undef G2_FENCE
+  if (dbg) ts3 = g2_clock();
 
-  epilogue_store<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, m0, n0, wm, wn, l31, h, 0);
+  if (vec4) g2_epilogue_finish<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, P, m0, n0, wm, wn, l31, h);
+  else epilogue_store_scalar<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, m0, n0, wm, wn, l31, h, 0);
+  if (dbg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ts4 = g2_clock();
+    if (threadIdx.x == 0) {
+      unsigned long long* o = a.dbg + (size_t)blockIdx.x * 8;
+      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = ts4;
+      o[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -592,10 +793,15 @@ extern "C" int ofx_pack_weights_planes(const float* W, int64_t sk, int64_t sn, i
 // ------------------------------------------------------------------------------------------------
 int ofx_launch_stats_reduce(const GemmArgs& g, int wr_rows, hipStream_t st);   // ofx_gemm.hip
 
-static int g2_variant = 0;
+static int g2_variant = 1;
 extern "C" int ofx_set_gconv2_variant(int v) {
   if (v < 0 || v > 1) return OFX_EINVAL;
   g2_variant = v;
+  return OFX_OK;
+}
+static unsigned long long* g2_debug = nullptr;
+extern "C" int ofx_set_gconv2_debug(void* buf) {
+  g2_debug = (unsigned long long*)buf;
   return OFX_OK;
 }
 
@@ -637,6 +843,7 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
   a.xp = (const char*)xp; a.ldx = ldx_bytes; a.aux = (const char*)aux; a.n_src = n_nodes; a.nbr_ext = nbr_ext;
   a.tfp = ntc ? (const char*)tfp : (const char*)xp; a.ldt = ntc ? ldt_bytes : ldx_bytes;
   a.W2 = (const char*)W2;
+  a.dbg = g2_debug;
   a.tpd = (int)(cin / ch); a.nkt_g = 7 * a.tpd; a.nkt = (int)ofx_planes_packed_ktiles(cin, nt, mode);
   GemmArgs& g = a.e;
   g.M = n_nodes; g.N = cout; g.K = g.Kp = (int64_t)a.nkt * ch; g.bias = bias; g.emb = emb; g.lde = lde; g.bid = batch_id;

@@ -40,7 +40,9 @@ def broadcast_module_(module, src=0):
     """Broadcast every parameter and buffer of `module` from `src` as ONE flat fp32 buffer."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    # the parameters themselves (not .data, which has its own version counter): copy_ below bumps _version, which is
+    # what the packed-weight caches key on -- a forward that ran before the broadcast cannot leave stale packs
+    tensors = list(module.parameters()) + list(module.buffers())
     tensors = [t for t in tensors if t.is_floating_point()]
     if not tensors:
         return 0

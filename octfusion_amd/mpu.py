@@ -20,15 +20,23 @@ class _TreeHandle:
         self.child = torch.cat([octree.children[d] for d in range(depth + 1)]).contiguous()
         self.key = torch.cat([octree.keys[d] for d in range(depth + 1)]).contiguous()
         self.nnum = [int(v) for v in octree.nnum[:depth + 1]]
+        self.sig = _TreeHandle.signature(octree)
         self._nnum_c = (ctypes.c_int64 * (depth + 1))(*self.nnum)
         self._nne_c = (ctypes.c_int64 * (depth + 1))(*[int(v) for v in octree.nnum_nempty[:depth + 1]])
         self.tree = _lib.OfxTree(depth, octree.full_depth, octree.batch_size, ptr(self.child), ptr(self.key), None,
                                  ctypes.addressof(self._nnum_c), ctypes.addressof(self._nne_c))
 
     @staticmethod
+    def signature(octree):
+        """identity of every per-depth array: octree_split / octree_grow REPLACE children[d] / keys[d] (also when the
+        node count does not change, e.g. the final split at depth_out), which must invalidate the handle"""
+        return tuple((octree.children[d].data_ptr(), octree.children[d]._version, octree.keys[d].data_ptr(),
+                      int(octree.nnum[d])) for d in range(octree.depth + 1))
+
+    @staticmethod
     def of(octree):
         h = getattr(octree, '_ofx_mpu_tree', None)
-        if h is None or h.nnum != [int(v) for v in octree.nnum[:octree.depth + 1]]:
+        if h is None or h.sig != _TreeHandle.signature(octree):
             h = _TreeHandle(octree)
             octree._ofx_mpu_tree = h
         return h

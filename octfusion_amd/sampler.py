@@ -88,17 +88,23 @@ def sample_loop(net, shape, batch_size, ddim_steps, unet_type, df_type, device, 
         st['cond'] = torch.zeros(batch_size, dtype=torch.float32, device=device)
         st['self'] = torch.zeros_like(x)
         st['noise'] = torch.zeros_like(x)
-    for i, (t, t_next) in enumerate(sampling_times(ddim_steps)):
-        noise_cond = beta_linear_log_snr(t).float().expand(batch_size).contiguous().to(device)
-        do_sign = float(t) < truncated_index and unet_type == 'lr'
-        if df_type == 'x0':
-            coef = x0_coef(t, t_next, truncated_index).to(device)
-            noise = None
-            if float(coef[3]) != 0.0:
-                noise = torch.randn_like(x) if step_noise is None else step_noise[i].to(device)
-        else:
-            coef = eps_coef(t, t_next).to(device)
-            noise = None
+    times = sampling_times(ddim_steps)
+    # every per-step scalar is computed on the host in fp32 (as the reference does) and uploaded ONCE:
+    # one [steps, 4] coefficient table and one [steps] log-SNR vector, indexed per step (no per-step H2D / D2H)
+    coef_host = torch.stack([x0_coef(t, tn, truncated_index) if df_type == 'x0' else eps_coef(t, tn)
+                             for t, tn in times])
+    coef_dev = coef_host.to(device)
+    cond_dev = torch.stack([beta_linear_log_snr(t).float() for t, _ in times]).to(device)
+    for i, (t, t_next) in enumerate(times):
+        noise_cond = cond_dev[i].expand(batch_size).contiguous()
+        # `t[0] < truncated_index` in the reference compares an fp32 tensor with a scalar IN fp32
+        # (octfusion_model_union.py:335): linspace(1, 0, steps+1) contains fp32(0.7) = 0.69999999 for
+        # steps = 10, 20, 50, 100, 200, where a double-precision compare would sign one step early
+        do_sign = bool(t < truncated_index) and unet_type == 'lr'
+        coef = coef_dev[i]
+        noise = None
+        if df_type == 'x0' and float(coef_host[i, 3]) != 0.0:
+            noise = torch.randn_like(x) if step_noise is None else step_noise[i].to(device)
         if not use_graph or i == 0:
             x0_out = torch.empty_like(x) if (df_type == 'eps' and wants_sc) else None
             x_start = _step(net, x, noise_cond, unet_type, df_type, doctree, unet_lr, label, x_start, coef, noise,

@@ -24,12 +24,40 @@ class AdamW:
     def step(self, grads):
         self.step_count += 1
         for k, p in self.params.items():
-            g = grads[k].contiguous()
+            g = grads.get(k)
+            if g is None:         # no gradient this step: torch.optim skips the parameter entirely (no decay either)
+                continue
+            g = g.contiguous()
             assert g.shape == p.shape, (k, g.shape, p.shape)
             m, v = self.state[k]
             call('ofx_adamw_step', ptr(p.data), ptr(g), ptr(m), ptr(v), p.numel(), self.lr, self.betas[0], self.betas[1],
                  self.eps, self.weight_decay, self.step_count, stream())
-            p.add_(0.0)           # the kernel wrote behind torch's back: bump the version so packed-weight caches repack
+            _bump(p)              # the kernel wrote behind torch's back: bump the version so packed-weight caches repack
+
+    def state_dict(self):
+        """{'step', 'state': {name: (exp_avg, exp_avg_sq)}} -- what checkpoint.save_ckpt stores under 'opt'."""
+        return {'step': self.step_count, 'state': {k: (m.clone(), v.clone()) for k, (m, v) in self.state.items()}}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd.get('step', 0))
+        for k, (m, v) in sd.get('state', {}).items():
+            if k in self.state:
+                self.state[k][0].copy_(m)
+                self.state[k][1].copy_(v)
+
+
+def _bump(p):
+    """Mark a tensor written by a libofx kernel as modified (what an in-place torch op would do) without
+    launching one."""
+    torch._C._increment_version(p)
+
+
+def trainable_parameters(net, stage):
+    """The parameters the reference optimises in `stage` ('lr' | 'hr' | 'feature'): only that stage's own net --
+    the earlier stages are frozen (requires_grad False, octfusion_model_union.py:127-142,
+    octfusion_model_union_3t.py:53-72) and AdamW is built from the trainable ones only."""
+    prefix = {'lr': 'unet_lr.', 'hr': 'unet_hr.', 'feature': 'unet_feature.'}[stage]
+    return {k: p for k, p in net.named_parameters() if k.startswith(prefix)}
 
 
 @torch.no_grad()
@@ -37,7 +65,7 @@ def ema_update(ema_module, module, beta):
     """ldm_diffusion_util.py:50-53."""
     for pe, p in zip(ema_module.parameters(), module.parameters()):
         call('ofx_ema_update', ptr(pe.data), ptr(p.data), p.numel(), beta, stream())
-        pe.add_(0.0)
+        _bump(pe)
 
 
 @torch.no_grad()
@@ -97,14 +125,12 @@ def hr_stage_step(net, opt, codes, doctree, depth, times=None, noise=None, label
         box['loss'] = float((diff * diff).mean())
         return diff * (2.0 / diff.numel())
     outer, nested = ('unet_hr', 'unet_lr') if stage == 'hr' else ('unet_feature', 'unet_hr')
-    _, _, g_o, g_n = BW.hr_unet_forward_backward(getattr(net, outer), noised, doctree, getattr(net, nested), log_snr,
-                                                 dy_fn, label=label)
+    _, _, g_o, _g_nested = BW.hr_unet_forward_backward(getattr(net, outer), noised, doctree, getattr(net, nested),
+                                                      log_snr, dy_fn, label=label)
+    # only the stage's own net is trained: the nested earlier-stage net is frozen in the reference
+    # (octfusion_model_union.py:127-142, octfusion_model_union_3t.py:53-72), so its gradients are dropped and
+    # parameters without a gradient are skipped by the optimiser (torch's grad=None behaviour: no update, no decay)
     grads = {outer + '.' + k: v for k, v in g_o.items()}
-    grads.update({nested + '.' + k: v for k, v in g_n.items()})
-    # parameters that take no part in this stage (the lr net's own input / output convolutions) keep a zero gradient
-    for k, p in opt.params.items():
-        if k not in grads:
-            grads[k] = torch.zeros_like(p)
     opt.step(grads)
     if ema is not None:
         ema_update(ema, net, ema_rate)

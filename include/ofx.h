@@ -298,7 +298,9 @@ int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes,
  * ofx_planes_split: fp32 -> planes (columns C..Cpad-1 zero-filled; in place allowed for mode 2).
  * ofx_planes_merge: planes -> fp32 (tests).
  * ofx_gn_apply_planes: ofx_gn_apply (modules.py:311-314 + fused SiLU/GELU) writing planes; `out` may be x
- *      itself in mode 2.
+ *      itself in mode 2.  With aux != NULL (then out must not alias x) the same launch also writes the consuming
+ *      GraphConv's aux rows (zero row + multi-neighbour means, from the CSR seg_ptr / col / multi_seg of that
+ *      graph depth), and ofx_graphconv_fwd_planes is called with aux_ready = 1: one launch less per convolution.
  * ofx_pack_weights_planes: GraphConv weights [7*(cin+nt'), cout] (element (k, n) at W[k*sk + n*sn]) ->
  *      [k tile][cout][128-B line], k order: 7*cin gathered channels direction-major, then the 7*nt node-type
  *      rows zero-padded to a whole tile; ofx_planes_packed_bytes() bytes.
@@ -312,7 +314,8 @@ int ofx_planes_merge(const void* planes, int64_t ldp_bytes, int64_t n, int C, in
                      void* stream);
 int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id, const float* mean,
                         const float* rstd, const float* w, const float* bias, int act, int mode, void* out,
-                        int64_t ldo_bytes, void* stream);
+                        int64_t ldo_bytes, const int32_t* seg_ptr, const int32_t* col, const int32_t* multi_seg,
+                        int64_t n_multi, void* aux /* optional */, void* stream);
 int64_t ofx_planes_packed_ktiles(int cin, int nt, int mode);
 int64_t ofx_planes_packed_bytes(int cin, int nt, int cout, int mode);
 int ofx_pack_weights_planes(const float* W, int64_t sk, int64_t sn, int cin, int nt, int cout, int mode, void* out,
@@ -322,9 +325,15 @@ int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int cin, int64_t
                              void* aux, const void* tfp, int64_t ldt_bytes, int nt, const void* W2, int cout,
                              const float* bias, const float* emb, int64_t lde, const int32_t* batch_id,
                              const float* res, int64_t ldr, float* out, int64_t ldc, double* stats /* optional */,
-                             int64_t stats_ld, void* ws, size_t ws_bytes, int mode, void* stream);
+                             int64_t stats_ld, void* ws, size_t ws_bytes, int mode, int aux_ready, void* stream);
 /* scheduling variant of the planes kernel (0: DMA requests before the MFMA group, 1: interleaved) -- A/B knob */
 int ofx_set_gconv2_variant(int v);
+/* block geometry of the planes kernel: 0 = automatic, 2 = 128 x 128 tiles (4 waves, two blocks per CU),
+ * 4 = 256 x 128 tiles (8 waves, one block per CU) -- A/B knob */
+int ofx_set_gconv2_tile(int wm);
+/* start offset between the two co-resident blocks of a CU (128-row geometry), in shader clocks per k tile of the
+ * layer; 0 = start together -- A/B knob */
+int ofx_set_gconv2_stagger(int clocks_per_ktile);
 /* profiling aid: when buf != NULL every block of the following ofx_graphconv_fwd_planes launches writes 8 uint64
  * to buf[block*8..]: shader-clock stamps at start / table built / first tile landed / k-loop done / stores drained,
  * then HW_ID.  buf must hold 8 * (tiles of the largest launch) uint64.  NULL switches it off. */

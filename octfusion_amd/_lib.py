@@ -85,14 +85,17 @@ _SIGS = {
                                 c_i, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_sz, c_p], True),
     'ofx_planes_split': (c_i, [c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_l, c_p], True),
     'ofx_planes_merge': (c_i, [c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p], True),
-    'ofx_gn_apply_planes': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_l, c_p], True),
+    'ofx_gn_apply_planes': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_l,
+                                  c_p, c_p], True),
     'ofx_planes_packed_ktiles': (c_l, [c_i, c_i, c_i], False),
     'ofx_planes_packed_bytes': (c_l, [c_i, c_i, c_i, c_i], False),
     'ofx_pack_weights_planes': (c_i, [c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_p], True),
     'ofx_graphconv_fwd_planes': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_i,
-                                       c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_sz, c_i, c_p], True),
+                                       c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_sz, c_i, c_i, c_p], True),
     'ofx_set_gconv2_variant': (c_i, [c_i], True),
     'ofx_set_gconv2_debug': (c_i, [c_p], True),
+    'ofx_set_gconv2_tile': (c_i, [c_i], True),
+    'ofx_set_gconv2_stagger': (c_i, [c_i], True),
     'ofx_graph_multi_flag': (c_i, [c_p, c_l, c_p, c_p], True),
     'ofx_graph_primary_ext': (c_i, [c_p, c_p, c_l, c_p, c_p, c_p, c_p], True),
     'ofx_graph_primary': (c_i, [c_p, c_p, c_l, c_p, c_p], True),

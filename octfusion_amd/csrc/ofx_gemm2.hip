@@ -35,15 +35,28 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef const char __attribute__((address_space(1)))* gcp;
 typedef __attribute__((address_space(3))) void* ldsp;
 
-constexpr int G2_BM = 256, G2_BN = 128;
-constexpr int G2_WM = 4, G2_WN = 2, G2_MI = 2, G2_NI = 2;
+// Two block geometries (template parameter WM = wave rows):
+//   WM = 4: 256 x 128 tile, 8 waves, 3 stage buffers (DMA two k-steps ahead), 152 KB LDS -> ONE block per CU;
+//   WM = 2: 128 x 128 tile, 4 waves, 2 stage buffers (DMA one k-step ahead),  68 KB LDS -> TWO blocks per CU: the
+//           prologue (table + first DMA), the epilogue (residual reads, stores) and every barrier wait of one
+//           block overlap the other block's MFMAs, at the price of 1/3 more operand bytes per MFMA (the weight tile
+//           is shared by 128 rows instead of 256).
+constexpr int G2_BN = 128;
+constexpr int G2_WN = 2, G2_MI = 2, G2_NI = 2;
 constexpr int G2_LINE = 128;                          // bytes per row per k-step (both precisions)
-constexpr int G2_A_BYTES = G2_BM * G2_LINE;           // 32 KB
 constexpr int G2_B_BYTES = G2_BN * G2_LINE;           // 16 KB
-constexpr int G2_BUF = G2_A_BYTES + G2_B_BYTES;       // 48 KB per stage
-constexpr int G2_NBUF = 3;
-constexpr int G2_TAB = G2_NBUF * G2_BUF;              // neighbour-table slice [256][8] uint32
-constexpr int G2_LDS = G2_TAB + G2_BM * 8 * 4;        // 155 648 B (of 163 840)
+template <int WM> struct G2Cfg {
+  static constexpr int BM = WM * G2_MI * 32;
+  static constexpr int WAVES = WM * G2_WN;
+  static constexpr int THREADS = WAVES * 64;
+  static constexpr int NBUF = WM == 4 ? 3 : 2;
+  static constexpr int A_BYTES = BM * G2_LINE;
+  static constexpr int BUF = A_BYTES + G2_B_BYTES;    // one stage
+  static constexpr int TAB = NBUF * BUF;              // neighbour-table slice [BM][8] uint32
+  static constexpr int LDS = TAB + BM * 8 * 4;        // 155 648 B (WM 4) / 69 632 B (WM 2)
+  static constexpr int B_PER_WAVE = (G2_BN / 8) / WAVES;              // weight-tile DMA instructions per wave: 2 / 4
+  static constexpr int GLDS = 4 + B_PER_WAVE;                         // DMA instructions per wave per k-step: 6 / 8
+};
 
 struct Gemm2Args {
   const char* xp; int64_t ldx;            // activation planes; row pitch in BYTES
@@ -54,6 +67,7 @@ struct Gemm2Args {
   const char* W2;                         // [nkt][N][128 B]
   int tpd, nkt_g, nkt;                    // k tiles per direction, gather tiles (7 * tpd), all tiles
   unsigned long long* dbg;                // optional [blocks][8] shader-clock stamps (ofx_set_gconv2_debug)
+  int stagger;                            // shader clocks the second block of each CU waits before its first tile (WM 2)
   GemmArgs e;                             // M, N, epilogue operands, tile grid
 };
 
@@ -280,11 +294,13 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
   }
 }
 
-constexpr int G2_GLDS_PER_STEP = 6;                   // DMA instructions per wave per k-step (4 A + 2 B)
 
-template <int PREC, int VARIANT>
-__global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
+template <int PREC, int VARIANT, int WM>
+__global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   // (a WM-dependent bound loses the host stub)
   typedef G2Half<PREC> Half;
+  typedef G2Cfg<WM> CF;
+  constexpr int G2_WM = WM, G2_BM = CF::BM, G2_A_BYTES = CF::A_BYTES, G2_BUF = CF::BUF, G2_TAB = CF::TAB;
+  constexpr int G2_GLDS_PER_STEP = CF::GLDS;
   extern __shared__ __attribute__((aligned(128))) char smem2[];
   const GemmArgs& g = a.e;
 
@@ -303,6 +319,15 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
   const int l31 = lane & 31, h = lane >> 5;
   const bool dbg = a.dbg != nullptr;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+  if (WM == 2 && a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    // Two blocks share a CU and all 512 first-round blocks start together, so their prologues, k-loops and
+    // epilogues coincide and nothing overlaps.  The second block of every CU (dispatch order observed on gfx950:
+    // block b -> XCD b % 8, CU (b / 8) % 32, i.e. blocks 256..511 are the second slots; only speed depends on this)
+    // idles for about half a tile once: the pair then stays out of phase for the whole launch and one block's
+    // table build / DMA latency / residual reads / stores run under the other block's MFMAs.
+    const unsigned long long t0 = g2_clock();
+    while (g2_clock() - t0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(32);
+  }
   if (dbg) ts0 = g2_clock();
 
   // ---- neighbour-table slice of this row tile -> LDS, already translated to unsigned 128-B LINE offsets:
@@ -317,7 +342,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
     const int64_t x_line = (a.xp - xlo) >> 7, aux_line = (a.aux - xlo) >> 7;   // all 128-B aligned (host-checked)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int e = threadIdx.x + 512 * t;
+      const int e = threadIdx.x + CF::THREADS * t;
       const int r = e >> 3, d = e & 7;
       int64_t m = m0 + r;
       m = m < mmax ? m : mmax;
@@ -357,14 +382,17 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
   const int swz0 = (lane >> 4) & 7, swz1 = (4 + (lane >> 4)) & 7;
   const int pa0 = (q8 ^ swz0) * 16, pa1 = (q8 ^ swz1) * 16;  // byte offset of the piece this lane fetches (j even / odd)
   const unsigned tab_lane = lds0 + G2_TAB + (wid * 32 + rsub) * 32;      // + j*256 + column*4
-  gcp wb0, wb1;
+  // weight tile: wave w stages columns [w * 8 * BPW, (w + 1) * 8 * BPW), 8 per DMA instruction
+  constexpr int BPW = CF::B_PER_WAVE;
+  gcp wb[4];                               // BPW <= 4 (a dependent bound here makes hipcc drop the host stub)
   {
     const int64_t Nc = g.N;
-    int64_t c0 = n0 + wid * 16 + rsub, c1 = c0 + 8;
-    c0 = c0 < Nc ? c0 : Nc - 1;
-    c1 = c1 < Nc ? c1 : Nc - 1;
-    wb0 = (gcp)a.W2 + c0 * G2_LINE + pa0;
-    wb1 = (gcp)a.W2 + c1 * G2_LINE + pa1;
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+      int64_t c = n0 + wid * (8 * BPW) + j * 8 + rsub;
+      c = c < Nc ? c : Nc - 1;
+      wb[j] = (gcp)a.W2 + c * G2_LINE + ((j & 1) ? pa1 : pa0);
+    }
   }
 
   // description of one k tile for the DMA stream (all wave-uniform)
@@ -385,10 +413,11 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
     for (int j = 0; j < 4; ++j)
       __builtin_amdgcn_global_load_lds(((j & 1) ? b1 : b0) + ((uint64_t)I.v[j] << 7),
                                        (ldsp)(abuf + j * (8 * G2_LINE)), 16, 0, 0);
-    char* const bbuf = smem2 + ob + G2_A_BYTES + wid * (16 * G2_LINE);
+    char* const bbuf = smem2 + ob + G2_A_BYTES + wid * (8 * BPW * G2_LINE);
     const int64_t wo = (int64_t)T.ktw * wstep;
-    __builtin_amdgcn_global_load_lds(wb0 + wo, (ldsp)(bbuf), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(wb1 + wo, (ldsp)(bbuf + 8 * G2_LINE), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < BPW; ++j)
+      __builtin_amdgcn_global_load_lds(wb[j] + wo, (ldsp)(bbuf + j * (8 * G2_LINE)), 16, 0, 0);
   };
   // tile `it` of the k order: channel chunk outer, direction inner over the 7 * tpd gather tiles, then the
   // node-type tiles (prologue only: the loops below advance (dir, chunk) incrementally)
@@ -419,6 +448,13 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
     }
   // 8 LDS reads: half c of the tile staged at byte offset ob
   auto read_half = [&](int ob, int c, Half& F) {
+    if (VARIANT == 4) {          // ablation: 8 cheap LDS reads (the waits count LDS ops), fragments keep stale registers
+      uint32_t d;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g2_ds_read32<0>(d, lds0 + G2_TAB);
+      asm volatile("" : G2_HALF_OPS(F));
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       g2_ds_read128<0>(F.a[u][0], fa[c][u] + ob);
@@ -440,6 +476,10 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto mfma_half = [&](const Half& F) {
+    if (VARIANT == 2) {          // ablation: keep one MFMA per half so the accumulators stay live
+      acc[0][0] = g2_mfma<PREC>(F.a[0][0], F.b[0][0], acc[0][0]);
+      return;
+    }
     if (PREC == 2) {
       // [0] = hi, [1] = lo: small cross terms first, the leading term last
 #pragma unroll
@@ -492,43 +532,73 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
   //   wait (tile it+1 landed, all own LDS reads done) + barrier | 8 reads: first half of tile it+1 -> F0 | MFMAs of F1
   // ob / obn / obnn: byte offsets of the stage buffers of tiles it, it+1, it+2 (rotating).
   int ob = 0, obn = G2_BUF, obnn = 2 * G2_BUF;
-  // `last`: the final steady-state step also REQUESTS the epilogue's operands (26 loads, issued before its DMA) so
-  // that they travel during the last ~2.5 k-steps; its barrier lets those 26 + the 6 new DMA stay outstanding.
+  // `last`: the final steady-state step also REQUESTS the epilogue's operands (26 loads) so that they travel during
+  // the last k-steps; its barrier lets those (and, with 3 stages, the 6 new DMA) stay outstanding.
   G2Epi<G2_MI, G2_NI> P;
   const bool vec4 = g.vec4 != 0;
+  constexpr int MFMA_PER_ROUND = (PREC == 2 ? 12 : 8) / G2_GLDS_PER_STEP > 0 ? (PREC == 2 ? 12 : 8) / G2_GLDS_PER_STEP : 1;
+  auto interleave_dma = [&]() {
+    // rounds of {MFMAs, address arithmetic, 1 DMA}: the DMA issues ride in the MFMAs' shadow
+#pragma unroll
+    for (int k = 0; k < G2_GLDS_PER_STEP; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, MFMA_PER_ROUND, 0);
+      __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+  };
   auto step_issue = [&](const Tile& T, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
-    load_idx(T, I);
-    read_half(ob, 1, F1);
-    g2_wait_lgkm<12, PREC>(F0);
-    G2_FENCE();
-    if (LAST) {
-      g2_epilogue_request<G2_WM, G2_WN, G2_MI, G2_NI>(g, (const void*)a.W2, P, m0, n0, wm, wn, l31, h);
+    if constexpr (CF::NBUF == 3) {
+      // 3 stages: tile it+2 is requested in the FIRST half of step it (its buffer was left at step it-1)
+      load_idx(T, I);
+      read_half(ob, 1, F1);
+      g2_wait_lgkm<12, PREC>(F0);
       G2_FENCE();
-    }
-    g2_wait_lgkm<8>(I);
-    issue(T, obnn, I);
-    if (VARIANT == 0) {
-      G2_FENCE();
-    }
-    mfma_half(F0);
-    if (VARIANT == 1) {
-      // rounds of {2 MFMA, address arithmetic, 1 DMA}: the DMA issues ride in the MFMAs' shadow
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (LAST) {
+        g2_epilogue_request<G2_WM, G2_WN, G2_MI, G2_NI>(g, (const void*)a.W2, P, m0, n0, wm, wn, l31, h);
+        G2_FENCE();
       }
+      g2_wait_lgkm<8>(I);
+      if (VARIANT != 3) issue(T, obnn, I);
+      if (VARIANT == 0) {
+        G2_FENCE();
+      }
+      mfma_half(F0);
+      if (VARIANT == 1) interleave_dma();
+      G2_FENCE();
+      g2_wait_barrier<(VARIANT == 3 ? 0 : G2_GLDS_PER_STEP) + (LAST ? G2_EPI_LOADS : 0), PREC>(F1);
+      G2_FENCE();
+      read_half(obn, 0, F0);
+      G2_FENCE();
+      mfma_half(F1);
+      G2_FENCE();
+      const int t = ob; ob = obn; obn = obnn; obnn = t;
+    } else {
+      // 2 stages: tile it+2 goes into the buffer tile `it` leaves at this step's barrier, i.e. it is requested in
+      // the SECOND half of step it and has one k-step to land (the co-resident block covers a late one)
+      read_half(ob, 1, F1);
+      g2_wait_lgkm<8, PREC>(F0);
+      G2_FENCE();
+      if (LAST) {
+        g2_epilogue_request<G2_WM, G2_WN, G2_MI, G2_NI>(g, (const void*)a.W2, P, m0, n0, wm, wn, l31, h);
+        G2_FENCE();
+      }
+      mfma_half(F0);
+      G2_FENCE();
+      g2_wait_barrier<(LAST ? G2_EPI_LOADS : 0), PREC>(F1);
+      G2_FENCE();
+      load_idx(T, I);
+      read_half(obn, 0, F0);
+      g2_wait_lgkm<8>(I);
+      if (VARIANT != 3) issue(T, ob, I);
+      if (VARIANT == 0) {
+        G2_FENCE();
+      }
+      mfma_half(F1);
+      if (VARIANT == 1) interleave_dma();
+      G2_FENCE();
+      const int t = ob; ob = obn; obn = t;
     }
-    G2_FENCE();
-    g2_wait_barrier<G2_GLDS_PER_STEP + (LAST ? G2_EPI_LOADS : 0), PREC>(F1);
-    G2_FENCE();
-    read_half(obn, 0, F0);
-    G2_FENCE();
-    mfma_half(F1);
-    G2_FENCE();
-    const int t = ob; ob = obn; obn = obnn; obnn = t;
   };
   // tile it+2 of the k order = (chunk gc, direction gd) while it is a gather tile, advanced without division
   int it = 0, gd = 2, gc = 0;                                      // nkt_g >= 7 > 2
@@ -561,7 +631,11 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {
     G2_FENCE();
     mfma_half(F1);
     G2_FENCE();
-    const int t = ob; ob = obn; obn = obnn; obnn = t;
+    if (CF::NBUF == 3) {
+      const int t = ob; ob = obn; obn = obnn; obnn = t;
+    } else {
+      const int t = ob; ob = obn; obn = t;
+    }
   }
   g2_epilogue_landed(P);
 #undef G2_FENCE
@@ -795,7 +869,7 @@ int ofx_launch_stats_reduce(const GemmArgs& g, int wr_rows, hipStream_t st);   /
 
 static int g2_variant = 1;
 extern "C" int ofx_set_gconv2_variant(int v) {
-  if (v < 0 || v > 1) return OFX_EINVAL;
+  if (v < 0 || v > 4) return OFX_EINVAL;
   g2_variant = v;
   return OFX_OK;
 }
@@ -805,16 +879,30 @@ extern "C" int ofx_set_gconv2_debug(void* buf) {
   return OFX_OK;
 }
 
-template <int PREC, int VARIANT>
+template <int PREC, int VARIANT, int WM>
 static int g2_launch(const Gemm2Args& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv2_kernel<PREC, VARIANT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv2_kernel<PREC, VARIANT, WM>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, G2Cfg<WM>::LDS) != hipSuccess)
       return OFX_ELAUNCH;
     attr_set = true;
   }
-  gconv2_kernel<PREC, VARIANT><<<a.e.ntm * a.e.ntn, 512, G2_LDS, st>>>(a);
+  gconv2_kernel<PREC, VARIANT, WM><<<a.e.ntm * a.e.ntn, G2Cfg<WM>::THREADS, G2Cfg<WM>::LDS, st>>>(a);
+  return OFX_OK;
+}
+
+// block geometry: 0 = automatic, 2 = 128-row tiles (two blocks per CU), 4 = 256-row tiles (one block per CU)
+static int g2_wm = 0;
+static int g2_stagger_per_ktile = 1100;     // shader clocks per k tile of the start offset between co-resident blocks
+extern "C" int ofx_set_gconv2_stagger(int clocks_per_ktile) {
+  if (clocks_per_ktile < 0 || clocks_per_ktile > 100000) return OFX_EINVAL;
+  g2_stagger_per_ktile = clocks_per_ktile;
+  return OFX_OK;
+}
+extern "C" int ofx_set_gconv2_tile(int wm) {
+  if (wm != 0 && wm != 2 && wm != 4) return OFX_EINVAL;
+  g2_wm = wm;
   return OFX_OK;
 }
 
@@ -824,7 +912,7 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
                                         int64_t ldt_bytes, int nt, const void* W2, int cout, const float* bias,
                                         const float* emb, int64_t lde, const int32_t* batch_id, const float* res,
                                         int64_t ldr, float* out, int64_t ldc, double* stats, int64_t stats_ld, void* ws,
-                                        size_t ws_bytes, int mode, void* stream) {
+                                        size_t ws_bytes, int mode, int aux_ready, void* stream) {
   if (mode != 1 && mode != 2) return OFX_EINVAL;
   const int64_t ch = g2_chunk(mode);
   if (n_nodes == 0 && cin >= 1 && cout >= 1) return OFX_OK;
@@ -837,8 +925,9 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
   if (ntc > 0 && (!tfp || (ldt_bytes & 15) || ((uintptr_t)tfp & 127))) return OFX_EINVAL;
   if (stats && (!batch_id || stats_ld < cout)) return OFX_EINVAL;
   hipStream_t st = ofx_stream(stream);
-  planes_multi_mean_kernel<<<ofx_grid((n_multi + 1) * (cin / 8), 256), 256, 0, st>>>(
-      (const char*)xp, ldx_bytes, cin, seg_ptr, col, multi_seg, n_multi, mode, (char*)aux);
+  if (!aux_ready)         // the producer of xp (ofx_gn_apply_planes / ofx_planes_split) may have written aux already
+    planes_multi_mean_kernel<<<ofx_grid((n_multi + 1) * (cin / 8), 256), 256, 0, st>>>(
+        (const char*)xp, ldx_bytes, cin, seg_ptr, col, multi_seg, n_multi, mode, (char*)aux);
   Gemm2Args a = {};
   a.xp = (const char*)xp; a.ldx = ldx_bytes; a.aux = (const char*)aux; a.n_src = n_nodes; a.nbr_ext = nbr_ext;
   a.tfp = ntc ? (const char*)tfp : (const char*)xp; a.ldt = ntc ? ldt_bytes : ldx_bytes;
@@ -853,7 +942,12 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
     g.vec4 = g.N % 4 == 0 && al16(g.out) && g.ldc % 4 == 0 && (!g.res || (al16(g.res) && g.ldr % 4 == 0)) &&
              (!g.emb || (al16(g.emb) && g.lde % 4 == 0)) && (!g.bias || al16(g.bias));
   }
-  g.ntm = (int)ofx_cdiv(g.M, G2_BM);
+  // geometry: one output-column tile (cout <= 128) -> 128-row tiles, two staggered blocks per CU (measured 3-9 %
+  // faster: prologue / epilogue overlap); several column tiles -> 256-row tiles, whose larger weight-tile reuse wins
+  // (cout 256 / 512 layers 5-15 % faster) -- profiles/r02/gconv2_geometry.txt
+  const int wm = g2_wm ? g2_wm : (cout <= 128 ? 2 : 4);
+  a.stagger = g2_stagger_per_ktile * a.nkt;
+  g.ntm = (int)ofx_cdiv(g.M, wm * 64);
   g.ntn = (int)ofx_cdiv(g.N, G2_BN);
   if (stats) {
     g.stats = stats; g.stats_ld = stats_ld;
@@ -863,8 +957,19 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
     }
   }
   int rc;
-  if (mode == 2) rc = g2_variant ? g2_launch<2, 1>(a, st) : g2_launch<2, 0>(a, st);
-  else rc = g2_variant ? g2_launch<1, 1>(a, st) : g2_launch<1, 0>(a, st);
+#define G2_GO(P_, V_) (wm == 4 ? g2_launch<P_, V_, 4>(a, st) : g2_launch<P_, V_, 2>(a, st))
+  if (mode == 2) {
+    switch (g2_variant) {
+      case 0: rc = G2_GO(2, 0); break;
+      case 2: rc = G2_GO(2, 2); break;      // ablations (wrong results): no MFMA / no DMA / no LDS reads
+      case 3: rc = G2_GO(2, 3); break;
+      case 4: rc = G2_GO(2, 4); break;
+      default: rc = G2_GO(2, 1); break;
+    }
+  } else {
+    rc = g2_variant == 0 ? G2_GO(1, 0) : G2_GO(1, 1);
+  }
+#undef G2_GO
   if (rc) return rc;
   if (g.stats_part) {
     rc = ofx_launch_stats_reduce(g, 64, st);

@@ -133,105 +133,166 @@ __device__ __forceinline__ float ofx_apply_act(float v, int act) {
   return v;
 }
 
-__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int C,
-                                                       const int32_t* __restrict__ bid, const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, int act, float* __restrict__ out,
-                                                       int64_t ldo) {
-  const int CT = C >> 2;
-  const int64_t total = n * CT;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = t / CT;
-    const int c = (int)(t - r * CT) * 4;
-    const int b = bid[r];
-    const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
-    const float4 m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c);
-    const float4 rs = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c);
-    const float4 ww = *reinterpret_cast<const float4*>(w + c);
-    const float4 bb = *reinterpret_cast<const float4*>(bias + c);
-    float4 o;
-    o.x = ofx_apply_act((v.x - m.x) * rs.x * ww.x + bb.x, act);
-    o.y = ofx_apply_act((v.y - m.y) * rs.y * ww.y + bb.y, act);
-    o.z = ofx_apply_act((v.z - m.z) * rs.z * ww.z + bb.z, act);
-    o.w = ofx_apply_act((v.w - m.w) * rs.w * ww.w + bb.w, act);
-    *reinterpret_cast<float4*>(out + r * ldo + c) = o;
-  }
-}
-
-extern "C" int ofx_gn_apply(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id, const float* mean,
-                            const float* rstd, const float* w, const float* bias, int act, float* out, int64_t ldo,
-                            void* stream) {
-  if (!x || !batch_id || !mean || !rstd || !w || !bias || !out || n < 0 || C < 4 || (C & 3) || ldx < C || ldo < C ||
-      (ldx & 3) || (ldo & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)w & 15) ||
-      ((uintptr_t)bias & 15) || ((uintptr_t)mean & 15) || ((uintptr_t)rstd & 15) || act < 0 || act > 2)
-    return OFX_EINVAL;
-  if (n > 0)
-    gn_apply_kernel<<<ofx_grid(n * (C / 4), 256), 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, batch_id, mean, rstd, w,
-                                                                                bias, act, out, ldo);
-  OFX_LAUNCH_CHECK();
-  return OFX_OK;
-}
-
-// Same normalisation, but the result leaves as OPERAND PLANES for the LDS-DMA GraphConv (ofx_gemm2.hip):
-// mode 2: per 32-channel chunk one 128-B line [bf16 hi x 32 | bf16 lo x 32] (y = hi + lo to 2^-17) -- the bytes
-// of the fp32 row, so `out` may alias an fp32-shaped buffer, including x itself (lane q of an 8-lane group reads
-// channels 4q..4q+3 of the chunk and writes bytes 8q..8q+7 of each half: every load of the wave instruction has
-// returned before any of its stores issues); mode 1: fp16 row-major.
+// Normalise + affine + activation, one read and one write of the tensor.  Block = 64 consecutive rows; thread =
+// (float4 of channels, row lane): the affine parameters are loaded ONCE per thread and (mean, rstd) only when the
+// batch element changes along its rows (the first version re-loaded all four per float4 -- five 16-B loads per 16 B of
+// payload -- and ran at 1.2 TB/s); four independent row loads in flight per lane.
+// MODE 0: fp32 rows out.  MODE 2 / 1: operand planes for the LDS-DMA GraphConv (ofx_gemm2.hip): 2 = per 32-channel
+// chunk one 128-B line [bf16 hi x 32 | bf16 lo x 32] (y = hi + lo to 2^-17) -- the bytes of the fp32 row, so `out` may
+// alias an fp32-shaped buffer, including x itself (a thread reads its 16 B of the chunk and writes 8 B of each half;
+// the 8 threads of a chunk are lanes of one wave instruction, whose loads all return before its stores issue);
+// 1 = fp16 row-major.
 __device__ __forceinline__ unsigned gn_pk_bf16(float a, float b) {
   unsigned r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-__global__ void __launch_bounds__(256) gn_apply_planes_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int C,
-                                                              const int32_t* __restrict__ bid,
-                                                              const float* __restrict__ mean,
-                                                              const float* __restrict__ rstd, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, int act, int mode,
-                                                              char* __restrict__ out, int64_t ldo) {
-  const int CT = C >> 2;
-  const int64_t total = n * CT;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = t / CT;
-    const int c = (int)(t - r * CT) * 4;
-    const int b = bid[r];
-    const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
-    const float4 m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c);
-    const float4 rs = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c);
-    const float4 ww = *reinterpret_cast<const float4*>(w + c);
-    const float4 bb = *reinterpret_cast<const float4*>(bias + c);
-    const float ox = ofx_apply_act((v.x - m.x) * rs.x * ww.x + bb.x, act);
-    const float oy = ofx_apply_act((v.y - m.y) * rs.y * ww.y + bb.y, act);
-    const float oz = ofx_apply_act((v.z - m.z) * rs.z * ww.z + bb.z, act);
-    const float ow = ofx_apply_act((v.w - m.w) * rs.w * ww.w + bb.w, act);
-    if (mode == 2) {
-      const unsigned h0 = gn_pk_bf16(ox, oy), h1 = gn_pk_bf16(oz, ow);
-      const unsigned l0 = gn_pk_bf16(ox - __uint_as_float(h0 << 16), oy - __uint_as_float(h0 & 0xffff0000u));
-      const unsigned l1 = gn_pk_bf16(oz - __uint_as_float(h1 << 16), ow - __uint_as_float(h1 & 0xffff0000u));
-      char* o = out + r * ldo + (c >> 5) * 128 + (c & 31) * 2;
+constexpr int GN_APPLY_ROWS = 64;
+template <int MODE>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int C,
+                                                       const int32_t* __restrict__ bid, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, int act, char* __restrict__ out,
+                                                       int64_t ldo, int64_t aux_blocks,
+                                                       const int32_t* __restrict__ seg_ptr,
+                                                       const int32_t* __restrict__ col,
+                                                       const int32_t* __restrict__ multi_seg, int64_t n_multi,
+                                                       char* __restrict__ aux) {
+  const int CT = C >> 2, RP = 256 / CT;
+  const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
+  if (rl >= RP) return;
+  const int c = cl * 4;
+  const float4 ww = *reinterpret_cast<const float4*>(w + c);
+  const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+  int cb = -1;
+  float4 m = make_float4(0.f, 0.f, 0.f, 0.f), rs = m;
+  auto norm = [&](int b, const float4& v) {
+    if (b != cb) {
+      cb = b;
+      m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c);
+      rs = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c);
+    }
+    return make_float4(ofx_apply_act((v.x - m.x) * rs.x * ww.x + bb.x, act),
+                       ofx_apply_act((v.y - m.y) * rs.y * ww.y + bb.y, act),
+                       ofx_apply_act((v.z - m.z) * rs.z * ww.z + bb.z, act),
+                       ofx_apply_act((v.w - m.w) * rs.w * ww.w + bb.w, act));
+  };
+  auto store = [&](char* orow, const float4& y) {
+    if (MODE == 0) {
+      *reinterpret_cast<float4*>(orow + (int64_t)c * 4) = y;
+    } else if (MODE == 2) {
+      const unsigned h0 = gn_pk_bf16(y.x, y.y), h1 = gn_pk_bf16(y.z, y.w);
+      const unsigned l0 = gn_pk_bf16(y.x - __uint_as_float(h0 << 16), y.y - __uint_as_float(h0 & 0xffff0000u));
+      const unsigned l1 = gn_pk_bf16(y.z - __uint_as_float(h1 << 16), y.w - __uint_as_float(h1 & 0xffff0000u));
+      char* o = orow + (c >> 5) * 128 + (c & 31) * 2;
       *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(o + 64) = make_uint2(l0, l1);
     } else {
-      const _Float16 a0 = (_Float16)ox, a1 = (_Float16)oy, a2 = (_Float16)oz, a3 = (_Float16)ow;
+      const _Float16 a0 = (_Float16)y.x, a1 = (_Float16)y.y, a2 = (_Float16)y.z, a3 = (_Float16)y.w;
       uint2 o;
       o.x = (unsigned)__builtin_bit_cast(unsigned short, a0) | ((unsigned)__builtin_bit_cast(unsigned short, a1) << 16);
       o.y = (unsigned)__builtin_bit_cast(unsigned short, a2) | ((unsigned)__builtin_bit_cast(unsigned short, a3) << 16);
-      *reinterpret_cast<uint2*>(out + r * ldo + c * 2) = o;
+      *reinterpret_cast<uint2*>(orow + c * 2) = o;
     }
+  };
+  if ((int64_t)blockIdx.x < aux_blocks) {
+    // ---- aux rows of the consuming GraphConv (its multi-neighbour pre-pass, folded into this launch): aux[0] = the
+    // zero row, aux[1 + v] = mean over segment multi_seg[v] of the NORMALISED source rows.  Reads the raw x (complete
+    // before this launch), so it does not depend on the main blocks -- out must not alias x when aux is requested.
+    // One aux row per (thread row lane): these are chains of dependent loads (segment -> column -> batch id -> row),
+    // so they get many small blocks at the FRONT of the grid and finish under the streaming main blocks.
+    const int64_t v = (int64_t)blockIdx.x * RP + rl;
+    if (v > n_multi) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v > 0) {
+      const int64_t sgm = multi_seg[v - 1];
+      const int32_t pa = seg_ptr[sgm], pe = seg_ptr[sgm + 1];
+      // segments of a dual-octree face hold 2, 4 or (rarely) more finer neighbours: groups of four with all column
+      // ids, then all batch ids and rows in flight together (a serial walk is a chain of 3 dependent loads per edge)
+      for (int32_t p0 = pa; p0 < pe; p0 += 4) {
+        int64_t sr[4];
+        int bb4[4];
+        float4 xv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sr[k] = col[p0 + k < pe ? p0 + k : pa];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bb4[k] = bid[sr[k]];
+          xv[k] = *reinterpret_cast<const float4*>(x + sr[k] * ldx + c);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 y = norm(bb4[k], xv[k]);
+          const float wgt = p0 + k < pe ? 1.f : 0.f;
+          acc.x += wgt * y.x; acc.y += wgt * y.y; acc.z += wgt * y.z; acc.w += wgt * y.w;
+        }
+      }
+      const float inv = 1.f / (float)(pe - pa);
+      acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    }
+    store(aux + v * ldo, acc);
+    return;
   }
+  const int64_t r_begin = ((int64_t)blockIdx.x - aux_blocks) * GN_APPLY_ROWS;
+  const int64_t r_end = r_begin + GN_APPLY_ROWS < n ? r_begin + GN_APPLY_ROWS : n;
+  int64_t r = r_begin + rl;
+  for (; r + 3 * (int64_t)RP < r_end; r += 4 * (int64_t)RP) {
+    const int b0 = bid[r], b1 = bid[r + RP], b2 = bid[r + 2 * RP], b3 = bid[r + 3 * RP];
+    const float4 v0 = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    const float4 v1 = *reinterpret_cast<const float4*>(x + (r + RP) * ldx + c);
+    const float4 v2 = *reinterpret_cast<const float4*>(x + (r + 2 * RP) * ldx + c);
+    const float4 v3 = *reinterpret_cast<const float4*>(x + (r + 3 * RP) * ldx + c);
+    store(out + r * ldo, norm(b0, v0));
+    store(out + (r + RP) * ldo, norm(b1, v1));
+    store(out + (r + 2 * RP) * ldo, norm(b2, v2));
+    store(out + (r + 3 * RP) * ldo, norm(b3, v3));
+  }
+  for (; r < r_end; r += RP) store(out + r * ldo, norm(bid[r], *reinterpret_cast<const float4*>(x + r * ldx + c)));
+}
+
+extern "C" int ofx_gn_apply(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id, const float* mean,
+                            const float* rstd, const float* w, const float* bias, int act, float* out, int64_t ldo,
+                            void* stream) {
+  if (!x || !batch_id || !mean || !rstd || !w || !bias || !out || n < 0 || C < 4 || (C & 3) || C > 1024 || ldx < C ||
+      ldo < C || (ldx & 3) || (ldo & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)w & 15) ||
+      ((uintptr_t)bias & 15) || ((uintptr_t)mean & 15) || ((uintptr_t)rstd & 15) || act < 0 || act > 2)
+    return OFX_EINVAL;
+  if (n > 0) {
+    const int64_t mb = ofx_cdiv(n, GN_APPLY_ROWS);
+    gn_apply_kernel<0><<<(int)mb, 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, batch_id, mean, rstd, w, bias, act,
+                                                                (char*)out, ldo * 4, 0, nullptr, nullptr, nullptr, 0,
+                                                                nullptr);
+  }
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
 }
 
 extern "C" int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,
                                    const float* mean, const float* rstd, const float* w, const float* bias, int act,
-                                   int mode, void* out, int64_t ldo_bytes, void* stream) {
+                                   int mode, void* out, int64_t ldo_bytes, const int32_t* seg_ptr, const int32_t* col,
+                                   const int32_t* multi_seg, int64_t n_multi, void* aux, void* stream) {
   const int chunk = mode == 2 ? 32 : 64;
   if ((mode != 1 && mode != 2) || !x || !batch_id || !mean || !rstd || !w || !bias || !out || n < 0 || C < chunk ||
-      (C % chunk) || ldx < C || (ldx & 3) || ldo_bytes < (int64_t)C * (mode == 2 ? 4 : 2) || (ldo_bytes & 15) ||
-      ((uintptr_t)x & 15) || ((uintptr_t)out & 127) || ((uintptr_t)w & 15) || ((uintptr_t)bias & 15) ||
-      ((uintptr_t)mean & 15) || ((uintptr_t)rstd & 15) || act < 0 || act > 2)
+      (C % chunk) || C > 1024 || ldx < C || (ldx & 3) || ldo_bytes < (int64_t)C * (mode == 2 ? 4 : 2) ||
+      (ldo_bytes & 15) || ((uintptr_t)x & 15) || ((uintptr_t)out & 127) || ((uintptr_t)w & 15) ||
+      ((uintptr_t)bias & 15) || ((uintptr_t)mean & 15) || ((uintptr_t)rstd & 15) || act < 0 || act > 2)
     return OFX_EINVAL;
-  if (n > 0)
-    gn_apply_planes_kernel<<<ofx_grid(n * (C / 4), 256), 256, 0, ofx_stream(stream)>>>(
-        x, ldx, n, C, batch_id, mean, rstd, w, bias, act, mode, (char*)out, ldo_bytes);
+  if (aux && (!seg_ptr || !col || n_multi < 0 || (n_multi > 0 && !multi_seg) || ((uintptr_t)aux & 127) ||
+              (const void*)out == (const void*)x))
+    return OFX_EINVAL;
+  if (n > 0) {
+    const int64_t mb = ofx_cdiv(n, GN_APPLY_ROWS);
+    const int64_t ab = aux ? ofx_cdiv(n_multi + 1, 256 / (C >> 2)) : 0;      // one aux row per row lane
+    const int grid = (int)(mb + ab);
+    if (mode == 2)
+      gn_apply_kernel<2><<<grid, 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, batch_id, mean, rstd, w, bias, act,
+                                                                (char*)out, ldo_bytes, ab, seg_ptr, col, multi_seg,
+                                                                n_multi, (char*)aux);
+    else
+      gn_apply_kernel<1><<<grid, 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, batch_id, mean, rstd, w, bias, act,
+                                                                (char*)out, ldo_bytes, ab, seg_ptr, col, multi_seg,
+                                                                n_multi, (char*)aux);
+  }
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }

@@ -71,6 +71,16 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def gather_floats(value, device):
+    """[value of rank 0, ..., value of rank W-1] on every rank (per-rank step times)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [value]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

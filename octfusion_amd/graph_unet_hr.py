@@ -116,6 +116,23 @@ class UNet3DModel(nn.Module):
         for p in self.out.parameters():          # zero_module (graph_unet_hr.py:209)
             p.detach().zero_()
 
+    def _all_emb_outs(self, emb_act):
+        """{id(block): emb_layers(emb)[B, Cout]} for every GraphResBlockEmbed of this net, from ONE GEMM."""
+        blocks = [m for m in self.modules() if isinstance(m, GraphResBlockEmbed)]
+        lins = [b.emb_layers[1] for b in blocks]
+        key = tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version) for l in lins)
+        if getattr(self, '_emb_cat_key', None) != key:
+            self._emb_cat_w = torch.cat([l.weight.detach() for l in lins], dim=0).contiguous()
+            self._emb_cat_b = torch.cat([l.bias.detach() for l in lins], dim=0).contiguous()
+            self._emb_cat_pw = ops.PackedWeight()
+            self._emb_cat_key = key
+        allout = ops.gemm(emb_act, self._emb_cat_pw.get(self._emb_cat_w, 'nk'), self._emb_cat_b)
+        outs, off = {}, 0
+        for b, l in zip(blocks, lins):
+            outs[id(b)] = allout[:, off:off + l.out_features]
+            off += l.out_features
+        return outs
+
     def forward_as_middle(self, h, doctree, timesteps, label, context):
         return self.forward(x=h, doctree=doctree, timesteps=timesteps, label=label, context=context,
                             as_middle=True)
@@ -136,6 +153,9 @@ class UNet3DModel(nn.Module):
             assert label.shape == (doctree.batch_size,)
             emb = emb + self.label_emb(label)
         emb_act = ops.act(emb, 'silu')          # SiLU(emb) is what every res-block consumes
+        # every res-block applies its own Linear(ted -> Cout) to the same SiLU(emb) (modules.py:754): one GEMM
+        # against the row-concatenated weights instead of one launch per block
+        emb_outs = self._all_emb_outs(emb_act)
 
         # Zero-copy skip concatenation: the decoder block that consumes skip tensor i reads ONE buffer
         # [N, C_h + C_skip]; the encoder module that produces the skip writes straight into its right
@@ -162,17 +182,17 @@ class UNet3DModel(nn.Module):
         for k, ((kind, dd, _), module) in enumerate(zip(self._enc, self.input_blocks[1:])):
             slot = skip_slot(k + 1)
             if kind == 'res':
-                h = module(h, emb, doctree, dd, emb_act=emb_act, out=slot)
+                h = module(h, emb, doctree, dd, emb_act=emb_act, out=slot, emb_out=emb_outs[id(module)])
             else:
                 h = module(h, doctree, dd, out=slot)
             hs.append(h)
         d = self._d_mid
 
         if unet_lr is not None:
-            h = self.middle_block1(h, emb, doctree, d, emb_act=emb_act)
+            h = self.middle_block1(h, emb, doctree, d, emb_act=emb_act, emb_out=emb_outs[id(self.middle_block1)])
             h_lr = unet_lr.forward_as_middle(h, doctree, timesteps, label, context)
             h = ops.cat_channels(h, h_lr)
-            h = self.middle_block2(h, emb, doctree, d, emb_act=emb_act)
+            h = self.middle_block2(h, emb, doctree, d, emb_act=emb_act, emb_out=emb_outs[id(self.middle_block2)])
 
         # decoder: block j consumes skip len(hs)-1-j; its own output goes to the left columns of the NEXT
         # consumer's buffer when the next module is a res block
@@ -196,7 +216,7 @@ class UNet3DModel(nn.Module):
                         setattr(left, ops.STATS_ATTR, st)
                     pending = left
                 hcat = ops.cat_channels(pending, hs[si], buf=cat_bufs[si])
-                pending = module(hcat, emb, doctree, dd, emb_act=emb_act, out=out_slot)
+                pending = module(hcat, emb, doctree, dd, emb_act=emb_act, out=out_slot, emb_out=emb_outs[id(module)])
                 j += 1
             else:
                 pending = module(pending, doctree, dd, out=out_slot)

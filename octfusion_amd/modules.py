@@ -130,13 +130,20 @@ class DualOctreeGroupNorm(nn.Module):
 
     @torch.no_grad()
     def forward(self, data, doctree, depth, act=None, out=None, planes=0):
-        """``planes``: write the result as operand planes of the LDS-DMA GraphConv (ops.planes_mode())."""
+        """``planes``: write the result as operand planes of the LDS-DMA GraphConv (ops.planes_mode()) together with
+        the aux rows (zero row + multi-neighbour means) that convolution gathers besides the tensor itself."""
         assert doctree.batch_id32(depth).shape[0] == data.shape[0]
         stats = ops.get_stats(data)
         if planes == 2 and out is not None and not ops.planes_ok(out, 2):
             out = None
+        aux_graph = None
+        if planes:
+            seg_ptr, col, _, _ = doctree.csr(depth)
+            _, multi_seg, n_multi = doctree.ext(depth)
+            aux_graph = (seg_ptr, col, multi_seg, n_multi)
         y = ops.group_norm(data, doctree.batch_id32(depth), doctree.count(depth), doctree.batch_size,
-                           self.weights, self.bias, self.group, self.eps, act, out, stats=stats, planes=planes)
+                           self.weights, self.bias, self.group, self.eps, act, out, stats=stats, planes=planes,
+                           aux_graph=aux_graph)
         if out is data and stats is not None:
             delattr(data, ops.STATS_ATTR)          # overwritten in place: the sums no longer describe it
         return y
@@ -341,13 +348,15 @@ class GraphResBlockEmbed(TimestepBlock):
             self.skip_connection = Conv1x1(self.channels, self.out_channels)
 
     @torch.no_grad()
-    def forward(self, x, emb, doctree, depth, emb_act=None, out=None):
-        """``emb_act``: optional precomputed SiLU(emb) shared by all blocks of a step; ``out``: optional
-        destination (may be a column slice of a wider buffer: zero-copy skip concatenation)."""
+    def forward(self, x, emb, doctree, depth, emb_act=None, out=None, emb_out=None):
+        """``emb_act``: optional precomputed SiLU(emb) shared by all blocks of a step; ``emb_out``: optional
+        precomputed emb_layers(emb) [B, Cout] (the U-Net evaluates the emb_layers of ALL its blocks in one GEMM);
+        ``out``: optional destination (may be a column slice of a wider buffer: zero-copy skip concatenation)."""
         h = self.block1_norm(x, doctree, depth, act='silu', planes=self.conv1.planes_mode(doctree, depth))
-        if emb_act is None:
-            emb_act = ops.act(emb, 'silu')
-        emb_out = self.emb_layers[1](emb_act)                       # [B, Cout]
+        if emb_out is None:
+            if emb_act is None:
+                emb_act = ops.act(emb, 'silu')
+            emb_out = self.emb_layers[1](emb_act)                   # [B, Cout]
         assert doctree.batch_size == emb_out.shape[0]
         h = self.conv1(h, doctree, depth, emb=emb_out)              # + emb_out[batch_id] fused
         h = self.block2_norm(h, doctree, depth, act='silu', out=h, planes=self.conv2.planes_mode(doctree, depth))

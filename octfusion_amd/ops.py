@@ -157,7 +157,11 @@ def graphconv_planes(xp, mode, seg_ptr, col, ext, pw, cin, nt, tf_planes=None, b
     out2, ldc = _row_major(out)
     assert out2 is out
     nbr_ext, multi_seg, n_multi = ext
-    aux = torch.empty((n_multi + 1) * ldx, dtype=torch.uint8, device=xp.device)
+    aux = getattr(xp, AUX_ATTR, None)           # written by the producer of xp (group_norm(..., aux_graph=))
+    aux_ready = 1 if aux is not None else 0
+    if aux is None:
+        aux = torch.empty((n_multi + 1) * ldx, dtype=torch.uint8, device=xp.device)
+    assert aux.numel() >= (n_multi + 1) * ldx
     lde = ldr = ldt = 0
     if emb is not None:
         emb, lde = _row_major(emb)
@@ -178,7 +182,7 @@ def graphconv_planes(xp, mode, seg_ptr, col, ext, pw, cin, nt, tf_planes=None, b
     call('ofx_graphconv_fwd_planes', ptr(xp), ldx, cin, N, ptr(seg_ptr), ptr(col), ptr(nbr_ext), ptr(multi_seg),
          n_multi, ptr(aux), ptr(tf_planes), ldt, nt, ptr(pw.t), pw.N, ptr(bias), ptr(emb), lde,
          ptr(batch_id) if (emb is not None or stats is not None) else None, ptr(res), ldr, ptr(out), ldc,
-         ptr(stats), pw.N, ptr(ws), ws.numel(), mode, stream())
+         ptr(stats), pw.N, ptr(ws), ws.numel(), mode, aux_ready, stream())
     if prof is not None:
         e1.record()
         E = col.numel()
@@ -520,8 +524,11 @@ def gather_mean(x, seg_ptr, col):
     return out
 
 
+AUX_ATTR = '_ofx_aux'
+
+
 def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, act=None, out=None,
-               count_eps=None, stats=None, rows_per_batch=None, planes=0):
+               count_eps=None, stats=None, rows_per_batch=None, planes=0, aux_graph=None):
     """DualOctreeGroupNorm (+ optional fused activation).  count_eps=0 gives torch.nn.GroupNorm.
     stats: fp64 [B, C, 2] sums already produced by the epilogue of the kernel that wrote x.
     rows_per_batch: every batch element owns that many CONTIGUOUS rows (dense grids) -> one fused launch."""
@@ -553,11 +560,22 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
     w = weight.detach().reshape(-1)
     b = bias.detach().reshape(-1)
     if planes:
-        # the consumer is the planes GraphConv: write its operand format directly (mode 2 may alias x)
+        # the consumer is the planes GraphConv: write its operand format directly.  aux_graph = (seg_ptr, col,
+        # multi_seg, n_multi) of the consumer's graph: the same launch then also writes its aux rows (zero row +
+        # multi-neighbour means), which needs a destination other than x.
+        if aux_graph is not None and out is not None and out.data_ptr() == x.data_ptr():
+            out = None
         out, ldo = _planes_out(n, C, planes, dev, out if planes == 2 else None)
+        aux = seg_ptr = col = multi_seg = None
+        n_multi = 0
+        if aux_graph is not None:
+            seg_ptr, col, multi_seg, n_multi = aux_graph
+            aux = torch.empty((n_multi + 1) * ldo, dtype=torch.uint8, device=dev)
         call('ofx_gn_apply_planes', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(w), ptr(b),
-             ACT[act], planes, ptr(out), ldo, stream())
+             ACT[act], planes, ptr(out), ldo, ptr(seg_ptr), ptr(col), ptr(multi_seg), n_multi, ptr(aux), stream())
         setattr(out, PLANES_ATTR, planes)
+        if aux is not None:
+            setattr(out, AUX_ATTR, aux)
         return out
     if out is None:
         out = torch.empty(n, C, dtype=torch.float32, device=dev)

@@ -33,15 +33,26 @@ class CascadeSampler:
         self.depths = list(cfg['input_depth'])
 
     @torch.no_grad()
+    def _seed(self, value):
+        torch.manual_seed(value)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(value)
+
     def sample(self, batch_size, ddim_steps=200, label=None, split_small=None, noises=None, sdf_resolution=None,
-               sdf_scale=0.9, use_graph=False):
+               sdf_scale=0.9, use_graph=None, seed=None, save_index=0):
         """Returns a dict with the per-stage results.  `noises` (optional) = dict of explicit
         init / step noise tensors per stage for reproducible runs.  sdf_resolution (e.g. 256) adds
-        out['sdfs'] [B, R, R, R] (needs the VAE)."""
+        out['sdfs'] [B, R, R, R] (needs the VAE).
+        seed / save_index: the reference's per-shape seeding of the 2-stage model -- seed_everything(seed +
+        save_index) before the lr loop, seed_everything(seed) before the hr loop (octfusion_model_union.py:372,390);
+        the 3-stage model does not reseed (octfusion_model_union_3t.py:168,184,204: commented out)."""
         noises = noises or {}
         out = {}
         S = 1 << self.full_depth
+        reseed = seed is not None and len(self.stages) == 2
         if split_small is None:
+            if seed is not None:
+                self._seed(seed + save_index if reseed else seed)
             n = noises.get('lr', {})
             split_small = sampler.sample_loop(
                 self.net, (batch_size, self.cfg['input_channels'][0], S, S, S), batch_size, ddim_steps, 'lr',
@@ -54,6 +65,8 @@ class CascadeSampler:
             return out
         doctree = DualOctree(octree)
         n = noises.get('hr', {})
+        if reseed:
+            self._seed(seed)
         x = sampler.sample_loop(self.net, (doctree.total_num, self.cfg['input_channels'][1]), batch_size, ddim_steps,
                                 'hr', self.df_type[1], self.device, doctree=doctree, unet_lr=self.net.unet_lr,
                                 label=label, init_noise=n.get('init'), step_noise=n.get('steps'), use_graph=use_graph)

@@ -71,13 +71,16 @@ def _step(net, x, noise_cond, unet_type, df_type, doctree, unet_lr, label, x_sel
 
 
 def sample_loop(net, shape, batch_size, ddim_steps, unet_type, df_type, device, doctree=None, unet_lr=None,
-                label=None, truncated_index=0.0, init_noise=None, step_noise=None, use_graph=False):
+                label=None, truncated_index=0.0, init_noise=None, step_noise=None, use_graph=None):
     """Run `ddim_steps` denoising steps; `net` is a graph_unet_union.UNet3DModel (or any callable with
     its keyword interface).  Noise comes from torch's device RNG unless given explicitly.
 
-    use_graph: every shape is static across the steps of a stage (the doctree is fixed), so after one eager
-    step the step is captured into a hipGraph per regime (sign / noise / first-step flags) and replayed with
-    x, log-SNR, coefficients, noise and the self-conditioning tensor in static device buffers."""
+    use_graph (default: on for HIP devices): every shape is static across the steps of a stage (the doctree is
+    fixed), so after one eager step the step is captured into a hipGraph per regime (sign / noise / first-step
+    flags) and replayed with x, log-SNR, coefficients, noise and the self-conditioning tensor in static device
+    buffers -- ~250 launches per step leave the host's critical path."""
+    if use_graph is None:
+        use_graph = torch.device(device).type == 'cuda' and isinstance(net, torch.nn.Module)
     x = torch.randn(shape, device=device) if init_noise is None else init_noise.to(device).clone()
     x = x.contiguous()
     wants_sc = getattr(net, 'wants_self_cond', True)

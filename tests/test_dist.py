@@ -56,3 +56,42 @@ def test_shard_rule():
     items = [shard_indices(10, r, 4) for r in range(4)]
     assert items[1] == [1, 5, 9]
     assert sorted(sum(items, [])) == list(range(10))
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher re-executes itself under torch.distributed.run with one rank per
+    GPU; --bootstrap-only stops after rendezvous + one broadcast + the max-reduction (no HIP call), on gloo here."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--bootstrap-only'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    rec = json.loads(line)
+    assert rec == {'bootstrap': 'ok', 'world': 2, 'max_rank_seen': 1.0, 'shard_of_10': [0, 2, 4, 6, 8]}
+
+
+def test_bench_rank_command_is_the_documented_one():
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.rank_bootstrap_cmd(['--gpus', '8', '--steps', '5'], 8, port=29511)
+    assert cmd[1:] == ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr',
+                       '127.0.0.1', '--master-port', '29511', os.path.join(ROOT, 'bench.py'), '--gpus', '8',
+                       '--steps', '5']
+
+
+def test_generate_shards_like_the_reference():
+    """train.py:166-185: result_index = iter_i * world + rank, stop at the total."""
+    sys.path.insert(0, ROOT)
+    from octfusion_amd.dist import shard_indices
+    world, total = 8, 21
+    for rank in range(world):
+        ref = []
+        it = 0
+        while it * world + rank < total:
+            ref.append(it * world + rank)
+            it += 1
+        assert shard_indices(total, rank, world) == ref

@@ -153,11 +153,11 @@ def test_full_width_feature_step():
     oc6 = split2octree_small(split.to(dev()), 6, 4)
     x6, y6, z6, _ = oc6.xyzb(6)
     sl = synthetic.shell8_split_large(x6.cpu(), y6.cpu(), z6.cpu())
-    oc8 = split2octree_large(oc6, sl.to(dev()), 8)
+    oc8 = split2octree_large(oc6, sl.to(dev()), 6)
     doc = DualOctree(oc8)
     assert doc.total_num == 448232
     o6 = OS.split2octree_small(split, 6, 4)
-    o8 = OS.split2octree_large(o6, sl, 8)
+    o8 = OS.split2octree_large(o6, sl, 6)
     o_doc = OD.OracleDualOctree(o8)
     o_doc.post_processing_for_docnn()
     net = UNet3DModel(**configs.unet_params('obja_uncond', 'feature'))
@@ -207,8 +207,8 @@ def test_per_layer_sweep():
     oc6 = split2octree_small(split.to(dev()), 6, 4)
     x6, y6, z6, _ = oc6.xyzb(6)
     sl = synthetic.shell8_split_large(x6.cpu(), y6.cpu(), z6.cpu())
-    doc = DualOctree(split2octree_large(oc6, sl.to(dev()), 8))
-    o_doc = OD.OracleDualOctree(OS.split2octree_large(OS.split2octree_small(split, 6, 4), sl, 8))
+    doc = DualOctree(split2octree_large(oc6, sl.to(dev()), 6))
+    o_doc = OD.OracleDualOctree(OS.split2octree_large(OS.split2octree_small(split, 6, 4), sl, 6))
     o_doc.post_processing_for_docnn()
     shapes = layer_shapes()
     assert len(shapes) >= 12

@@ -1034,7 +1034,7 @@ def test_sample_loop_hipgraph_replay(golden):
     shp = (doc.total_num, 3)
     init = torch.randn(shp)
     ya = sampler.sample_loop(net, shp, doc.batch_size, 6, 'hr', 'eps', dev(), doctree=doc, unet_lr=net.unet_lr,
-                             init_noise=init)
+                             init_noise=init, use_graph=False)
     yb = sampler.sample_loop(net, shp, doc.batch_size, 6, 'hr', 'eps', dev(), doctree=doc, unet_lr=net.unet_lr,
                              init_noise=init, use_graph=True)
     close(yb, ya, 1e-5)

@@ -76,8 +76,8 @@ for d, cin, cout in shapes:
         xp = ops.planes_split(x, mode)
         back = ops.planes_merge(xp, mode)
         out['%s_split_err' % prec] = relmax(back, x)
-        for variant in (0, 1):
-            _lib.call('ofx_set_gconv2_variant', variant)
+        for variant in (0, 1):          # here: tile geometry 4 (256 rows, 1 block/CU) vs 2 (128 rows, 2 blocks/CU)
+            _lib.call('ofx_set_gconv2_tile', 4 if variant == 0 else 2)
             y2 = conv(xp, doc, d, emb=emb, res=res)
             torch.cuda.synchronize()
             err = relmax(y2, y_ref)
@@ -98,6 +98,7 @@ for d, cin, cout in shapes:
         t_split = timeit(lambda: ops.planes_split(x, mode))
         out['%s_split_ms' % prec] = t_split
     ops.set_precision('bf16x3')
+    _lib.call('ofx_set_gconv2_tile', 0)
     rows.append(out)
     print(json.dumps(out))
     sys.stdout.flush()

@@ -14,7 +14,12 @@ dev = torch.device('cuda:0')
 torch.set_grad_enabled(False)
 doc = DualOctree(split2octree_small(synthetic.shell6_split(8).to(dev), 6, 4))
 ops.PLANES_MIN_TILES = 1
-for d, cin, cout, epi in [(6, 128, 128, True), (6, 128, 128, False), (6, 384, 128, True), (5, 256, 256, True)]:
+import itertools
+VARIANTS = [int(v) for v in os.environ.get("G2_VARIANTS", "1").split(",")]
+TILES = [int(v) for v in os.environ.get("G2_TILES", "2,4").split(",")]
+for (d, cin, cout, epi), variant, tile in itertools.product([(6, 128, 128, True), (6, 128, 128, False), (6, 384, 128, True), (5, 256, 256, True)], VARIANTS, TILES):
+    _lib.call("ofx_set_gconv2_variant", variant)
+    _lib.call("ofx_set_gconv2_tile", tile)
     N = doc.csr(d)[2]
     conv = M.GraphConv(cin, cout, 7, 7, d - 1).to(dev)
     conv.emit_stats = False
@@ -23,7 +28,7 @@ for d, cin, cout, epi in [(6, 128, 128, True), (6, 128, 128, False), (6, 384, 12
     res = torch.randn(N, cout, device=dev) if epi else None
     for _ in range(3):
         conv(xp, doc, d, emb=emb, res=res)
-    nblk = ((N + 255) // 256) * ((cout + 127) // 128)
+    nblk = ((N + 64 * tile - 1) // (64 * tile)) * ((cout + 127) // 128)
     buf = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
     _lib.call('ofx_set_gconv2_debug', buf.data_ptr())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,7 +41,7 @@ for d, cin, cout, epi in [(6, 128, 128, True), (6, 128, 128, False), (6, 384, 12
     t0 = t[:, 0].min()
     seg = [(t[:, i + 1] - t[:, i]) for i in range(4)]
     span = (t[:, 4].max() - t0)
-    print('d%d %d->%d epi=%s: blocks %d, launch %.1f us (events), span %.0f ticks' % (d, cin, cout, epi, nblk, e0.elapsed_time(e1) * 1e3, span))
+    print('d%d %d->%d epi=%s variant %d tile %d: blocks %d, launch %.1f us (events)' % (d, cin, cout, epi, variant, tile * 64, nblk, e0.elapsed_time(e1) * 1e3))
     for name, s in zip(('table', 'first-dma', 'k-loop', 'epilogue'), seg):
         print('   %-10s mean %8.0f  min %8.0f  max %8.0f ticks' % (name, s.mean(), s.min(), s.max()))
     start = t[:, 0] - t0

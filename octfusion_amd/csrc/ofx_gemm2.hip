@@ -41,20 +41,25 @@ typedef __attribute__((address_space(3))) void* ldsp;
 //           prologue (table + first DMA), the epilogue (residual reads, stores) and every barrier wait of one
 //           block overlap the other block's MFMAs, at the price of 1/3 more operand bytes per MFMA (the weight tile
 //           is shared by 128 rows instead of 256).
-constexpr int G2_BN = 128;
-constexpr int G2_WN = 2, G2_MI = 2, G2_NI = 2;
+// Output width: NI = 2 -> 128-column tiles (wave tile 64 x 64); NI = 1 -> 64-column tiles (wave tile 64 x 32) for the
+// cout <= 64 layers (the depth-8 layers of the 3-stage feature net), which would waste half their MFMAs on clamped
+// columns of a 128-wide tile.
+constexpr int G2_WN = 2, G2_MI = 2;
 constexpr int G2_LINE = 128;                          // bytes per row per k-step (both precisions)
-constexpr int G2_B_BYTES = G2_BN * G2_LINE;           // 16 KB
-template <int WM> struct G2Cfg {
+template <int WM, int NI = 2> struct G2Cfg {
+  static constexpr int BN = G2_WN * NI * 32;
+  static constexpr int B_BYTES = BN * G2_LINE;
   static constexpr int BM = WM * G2_MI * 32;
   static constexpr int WAVES = WM * G2_WN;
   static constexpr int THREADS = WAVES * 64;
   static constexpr int NBUF = WM == 4 ? 3 : 2;
   static constexpr int A_BYTES = BM * G2_LINE;
-  static constexpr int BUF = A_BYTES + G2_B_BYTES;    // one stage
+  static constexpr int BUF = A_BYTES + B_BYTES;       // one stage
   static constexpr int TAB = NBUF * BUF;              // neighbour-table slice [BM][8] uint32
   static constexpr int LDS = TAB + BM * 8 * 4;        // 155 648 B (WM 4) / 69 632 B (WM 2)
-  static constexpr int B_PER_WAVE = (G2_BN / 8) / WAVES;              // weight-tile DMA instructions per wave: 2 / 4
+  static constexpr int B_PER_WAVE = (BN / 8) / WAVES;                 // weight-tile DMA instructions per wave: 1, 2 or 4
+  static constexpr int READS = 2 * (G2_MI + NI);                      // LDS reads of one half-step fragment set
+  static constexpr int EPI_LOADS = G2_MI * NI * 4 + NI + G2_MI * 4;   // epilogue operand requests per lane (26 / 17)
   static constexpr int GLDS = 4 + B_PER_WAVE;                         // DMA instructions per wave per k-step: 6 / 8
 };
 
@@ -105,25 +110,51 @@ __device__ __forceinline__ void g2_ds_read32(uint32_t& d, unsigned addr) {
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
 // half-step fragment set: two piece classes of every A / B fragment of the 64 x 64 wave tile
-template <int PREC> struct G2Half { typename G2Frag<PREC>::T a[2][G2_MI], b[2][G2_NI]; };
-#define G2_HALF_OPS(F)                                                                                        \
-  "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[0][1]),      \
-      "+v"(F.b[1][0]), "+v"(F.b[1][1])
+template <int PREC, int NI> struct G2Half { typename G2Frag<PREC>::T a[2][G2_MI], b[2][NI]; };
 // wait until at most N younger LDS reads of this wave are outstanding; guards fragment set F
 template <int N, int PREC>
-__device__ __forceinline__ void g2_wait_lgkm(G2Half<PREC>& F) {
-  asm volatile("s_waitcnt lgkmcnt(%8)" : G2_HALF_OPS(F) : "n"(N));
+__device__ __forceinline__ void g2_wait_lgkm(G2Half<PREC, 2>& F) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[0][1]),
+                 "+v"(F.b[1][0]), "+v"(F.b[1][1])
+               : "n"(N));
+}
+template <int N, int PREC>
+__device__ __forceinline__ void g2_wait_lgkm(G2Half<PREC, 1>& F) {
+  asm volatile("s_waitcnt lgkmcnt(%6)"
+               : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[1][0])
+               : "n"(N));
+}
+// wait for all but the newest VM DMA instructions of this wave and for ALL its LDS reads (guarding F), then meet
+// the block.  The memory clobber keeps DMA issues and LDS traffic on their side of the barrier.
+template <int VM, int PREC>
+__device__ __forceinline__ void g2_wait_barrier(G2Half<PREC, 2>& F) {
+  asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)\n\ts_barrier"
+               : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[0][1]),
+                 "+v"(F.b[1][0]), "+v"(F.b[1][1])
+               : "n"(VM)
+               : "memory");
+}
+template <int VM, int PREC>
+__device__ __forceinline__ void g2_wait_barrier(G2Half<PREC, 1>& F) {
+  asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)\n\ts_barrier"
+               : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[1][0])
+               : "n"(VM)
+               : "memory");
+}
+template <int PREC>
+__device__ __forceinline__ void g2_touch(G2Half<PREC, 2>& F) {
+  asm volatile("" : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[0][1]),
+               "+v"(F.b[1][0]), "+v"(F.b[1][1]));
+}
+template <int PREC>
+__device__ __forceinline__ void g2_touch(G2Half<PREC, 1>& F) {
+  asm volatile("" : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[1][0]));
 }
 struct G2Idx { uint32_t v[4]; };
 template <int N>
 __device__ __forceinline__ void g2_wait_lgkm(G2Idx& I) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(I.v[0]), "+v"(I.v[1]), "+v"(I.v[2]), "+v"(I.v[3]) : "n"(N));
-}
-// wait for all but the newest VM DMA instructions of this wave and for ALL its LDS reads (guarding F), then meet
-// the block.  The memory clobber keeps DMA issues and LDS traffic on their side of the barrier.
-template <int VM, int PREC>
-__device__ __forceinline__ void g2_wait_barrier(G2Half<PREC>& F) {
-  asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)\n\ts_barrier" : G2_HALF_OPS(F) : "n"(VM) : "memory");
 }
 template <int VM>
 __device__ __forceinline__ void g2_wait_barrier() {
@@ -144,7 +175,6 @@ struct G2Epi {
   g2_v4f bias[NI];
   int bids[MI][4];
 };
-constexpr int G2_EPI_LOADS = G2_MI * G2_NI * 4 + G2_NI + G2_MI * 4;      // 26 VMEM loads, always
 
 // The requests are inline asm: their NUMBER enters a counted s_waitcnt vmcnt(N) of the k-loop (the DMA of the next
 // tile must be waited for without waiting for these), so the compiler must neither merge, drop nor reorder them.
@@ -187,14 +217,19 @@ __device__ __forceinline__ void g2_epilogue_request(const GemmArgs& g, const voi
   }
 }
 // after the vmcnt(0) of the last k-steps: ties every requested register to this point of the instruction stream
-template <int MI, int NI>
-__device__ __forceinline__ void g2_epilogue_landed(G2Epi<MI, NI>& P) {
-  static_assert(MI == 2 && NI == 2, "operand list written for the 64 x 64 wave tile");
+__device__ __forceinline__ void g2_epilogue_landed(G2Epi<2, 2>& P) {
   asm volatile("" : "+v"(P.res[0][0][0]), "+v"(P.res[0][0][1]), "+v"(P.res[0][0][2]), "+v"(P.res[0][0][3]),
                     "+v"(P.res[0][1][0]), "+v"(P.res[0][1][1]), "+v"(P.res[0][1][2]), "+v"(P.res[0][1][3]),
                     "+v"(P.res[1][0][0]), "+v"(P.res[1][0][1]), "+v"(P.res[1][0][2]), "+v"(P.res[1][0][3]),
                     "+v"(P.res[1][1][0]), "+v"(P.res[1][1][1]), "+v"(P.res[1][1][2]), "+v"(P.res[1][1][3]),
                     "+v"(P.bias[0]), "+v"(P.bias[1]));
+  asm volatile("" : "+v"(P.bids[0][0]), "+v"(P.bids[0][1]), "+v"(P.bids[0][2]), "+v"(P.bids[0][3]),
+                    "+v"(P.bids[1][0]), "+v"(P.bids[1][1]), "+v"(P.bids[1][2]), "+v"(P.bids[1][3]));
+}
+__device__ __forceinline__ void g2_epilogue_landed(G2Epi<2, 1>& P) {
+  asm volatile("" : "+v"(P.res[0][0][0]), "+v"(P.res[0][0][1]), "+v"(P.res[0][0][2]), "+v"(P.res[0][0][3]),
+                    "+v"(P.res[1][0][0]), "+v"(P.res[1][0][1]), "+v"(P.res[1][0][2]), "+v"(P.res[1][0][3]),
+                    "+v"(P.bias[0]));
   asm volatile("" : "+v"(P.bids[0][0]), "+v"(P.bids[0][1]), "+v"(P.bids[0][2]), "+v"(P.bids[0][3]),
                     "+v"(P.bids[1][0]), "+v"(P.bids[1][1]), "+v"(P.bids[1][2]), "+v"(P.bids[1][3]));
 }
@@ -295,10 +330,11 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
 }
 
 
-template <int PREC, int VARIANT, int WM>
+template <int PREC, int VARIANT, int WM, int NI>
 __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   // (a WM-dependent bound loses the host stub)
-  typedef G2Half<PREC> Half;
-  typedef G2Cfg<WM> CF;
+  typedef G2Half<PREC, NI> Half;
+  typedef G2Cfg<WM, NI> CF;
+  constexpr int G2_NI = NI, G2_BN = CF::BN, G2_EPI_LOADS = CF::EPI_LOADS, RH = CF::READS;
   constexpr int G2_WM = WM, G2_BM = CF::BM, G2_A_BYTES = CF::A_BYTES, G2_BUF = CF::BUF, G2_TAB = CF::TAB;
   constexpr int G2_GLDS_PER_STEP = CF::GLDS;
   extern __shared__ __attribute__((aligned(128))) char smem2[];
@@ -444,15 +480,15 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
       const int t = PREC == 2 ? (u == 0 ? c : 2 + c) : 2 * c + u;
       const int po = ((2 * t + h) ^ s7) * 16;
       fa[c][u] = lds0 + (wm * 64 + l31) * G2_LINE + po;
-      fb[c][u] = lds0 + G2_A_BYTES + (wn * 64 + l31) * G2_LINE + po;
+      fb[c][u] = lds0 + G2_A_BYTES + (wn * (32 * G2_NI) + l31) * G2_LINE + po;
     }
   // 8 LDS reads: half c of the tile staged at byte offset ob
   auto read_half = [&](int ob, int c, Half& F) {
     if (VARIANT == 4) {          // ablation: 8 cheap LDS reads (the waits count LDS ops), fragments keep stale registers
       uint32_t d;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) g2_ds_read32<0>(d, lds0 + G2_TAB);
-      asm volatile("" : G2_HALF_OPS(F));
+      for (int u = 0; u < RH; ++u) g2_ds_read32<0>(d, lds0 + G2_TAB);
+      g2_touch(F);
       return;
     }
 #pragma unroll
@@ -463,7 +499,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       g2_ds_read128<0>(F.b[u][0], fb[c][u] + ob);
-      g2_ds_read128<32 * G2_LINE>(F.b[u][1], fb[c][u] + ob);
+      if constexpr (NI == 2) g2_ds_read128<32 * G2_LINE>(F.b[u][1], fb[c][u] + ob);
     }
   };
 
@@ -536,7 +572,8 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
   // the last k-steps; its barrier lets those (and, with 3 stages, the 6 new DMA) stay outstanding.
   G2Epi<G2_MI, G2_NI> P;
   const bool vec4 = g.vec4 != 0;
-  constexpr int MFMA_PER_ROUND = (PREC == 2 ? 12 : 8) / G2_GLDS_PER_STEP > 0 ? (PREC == 2 ? 12 : 8) / G2_GLDS_PER_STEP : 1;
+  constexpr int MFMAS = (PREC == 2 ? 3 : 2) * G2_MI * G2_NI;
+  constexpr int MFMA_PER_ROUND = MFMAS / G2_GLDS_PER_STEP > 0 ? MFMAS / G2_GLDS_PER_STEP : 1;
   auto interleave_dma = [&]() {
     // rounds of {MFMAs, address arithmetic, 1 DMA}: the DMA issues ride in the MFMAs' shadow
 #pragma unroll
@@ -552,13 +589,13 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
       // 3 stages: tile it+2 is requested in the FIRST half of step it (its buffer was left at step it-1)
       load_idx(T, I);
       read_half(ob, 1, F1);
-      g2_wait_lgkm<12, PREC>(F0);
+      g2_wait_lgkm<4 + RH, PREC>(F0);
       G2_FENCE();
       if (LAST) {
         g2_epilogue_request<G2_WM, G2_WN, G2_MI, G2_NI>(g, (const void*)a.W2, P, m0, n0, wm, wn, l31, h);
         G2_FENCE();
       }
-      g2_wait_lgkm<8>(I);
+      g2_wait_lgkm<RH>(I);
       if (VARIANT != 3) issue(T, obnn, I);
       if (VARIANT == 0) {
         G2_FENCE();
@@ -577,7 +614,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
       // 2 stages: tile it+2 goes into the buffer tile `it` leaves at this step's barrier, i.e. it is requested in
       // the SECOND half of step it and has one k-step to land (the co-resident block covers a late one)
       read_half(ob, 1, F1);
-      g2_wait_lgkm<8, PREC>(F0);
+      g2_wait_lgkm<RH, PREC>(F0);
       G2_FENCE();
       if (LAST) {
         g2_epilogue_request<G2_WM, G2_WN, G2_MI, G2_NI>(g, (const void*)a.W2, P, m0, n0, wm, wn, l31, h);
@@ -589,7 +626,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
       G2_FENCE();
       load_idx(T, I);
       read_half(obn, 0, F0);
-      g2_wait_lgkm<8>(I);
+      g2_wait_lgkm<RH>(I);
       if (VARIANT != 3) issue(T, ob, I);
       if (VARIANT == 0) {
         G2_FENCE();
@@ -621,7 +658,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
   }
   for (; it < nkt; ++it) {                       // last two tiles: nothing left to request
     read_half(ob, 1, F1);
-    g2_wait_lgkm<8, PREC>(F0);
+    g2_wait_lgkm<RH, PREC>(F0);
     G2_FENCE();
     mfma_half(F0);
     G2_FENCE();
@@ -879,16 +916,16 @@ extern "C" int ofx_set_gconv2_debug(void* buf) {
   return OFX_OK;
 }
 
-template <int PREC, int VARIANT, int WM>
+template <int PREC, int VARIANT, int WM, int NI>
 static int g2_launch(const Gemm2Args& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv2_kernel<PREC, VARIANT, WM>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, G2Cfg<WM>::LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv2_kernel<PREC, VARIANT, WM, NI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, G2Cfg<WM, NI>::LDS) != hipSuccess)
       return OFX_ELAUNCH;
     attr_set = true;
   }
-  gconv2_kernel<PREC, VARIANT, WM><<<a.e.ntm * a.e.ntn, G2Cfg<WM>::THREADS, G2Cfg<WM>::LDS, st>>>(a);
+  gconv2_kernel<PREC, VARIANT, WM, NI><<<a.e.ntm * a.e.ntn, G2Cfg<WM, NI>::THREADS, G2Cfg<WM, NI>::LDS, st>>>(a);
   return OFX_OK;
 }
 
@@ -948,7 +985,8 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
   const int wm = g2_wm ? g2_wm : (cout <= 128 ? 2 : 4);
   a.stagger = g2_stagger_per_ktile * a.nkt;
   g.ntm = (int)ofx_cdiv(g.M, wm * 64);
-  g.ntn = (int)ofx_cdiv(g.N, G2_BN);
+  const int ni = cout <= 64 ? 1 : 2;              // 64-column tiles for the narrow layers
+  g.ntn = (int)ofx_cdiv(g.N, 64 * ni);
   if (stats) {
     g.stats = stats; g.stats_ld = stats_ld;
     const int64_t nwr = ofx_cdiv(g.M, 64);
@@ -957,7 +995,9 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
     }
   }
   int rc;
-#define G2_GO(P_, V_) (wm == 4 ? g2_launch<P_, V_, 4>(a, st) : g2_launch<P_, V_, 2>(a, st))
+#define G2_GO(P_, V_)                                                                               \
+  (ni == 1 ? (wm == 4 ? g2_launch<P_, V_, 4, 1>(a, st) : g2_launch<P_, V_, 2, 1>(a, st))             \
+           : (wm == 4 ? g2_launch<P_, V_, 4, 2>(a, st) : g2_launch<P_, V_, 2, 2>(a, st)))
   if (mode == 2) {
     switch (g2_variant) {
       case 0: rc = G2_GO(2, 0); break;

@@ -51,15 +51,16 @@ class GraphConv(nn.Module):
         self._pw2 = ops.PackedPlanes()
         self.emit_stats = True
 
-    def planes_mode(self, doctree, d):
+    def planes_mode(self, doctree, d, cin=None):
         """Operand-plane format this layer wants its input in (0: plain fp32 rows): the LDS-DMA kernel takes the
         layers with enough 256 x 128 tiles and whole 32 (64)-channel chunks."""
         mode = ops.planes_mode()
         if not mode:
             return 0
+        cin = self.in_channels if cin is None else (cin if mode == 2 else 64)
         N = doctree.csr(d)[2]
         tiles = ((N + 255) // 256) * ((self.out_channels + 127) // 128)
-        if (self.in_channels % (32 if mode == 2 else 64) or self.out_channels % 4 or self.out_channels < 64 or
+        if (cin % (32 if mode == 2 else 64) or self.out_channels % 4 or self.out_channels < 64 or
                 tiles < ops.PLANES_MIN_TILES):
             return 0
         return mode
@@ -86,13 +87,22 @@ class GraphConv(nn.Module):
         if self.emit_stats and N * self.out_channels >= (1 << 20) and self.out_channels % 4 == 0:
             stats = ops.stats_zeros(doctree.batch_size * self.out_channels * 2, x.device)
         mode = ops.planes_of(x)
+        cin_k = self.in_channels
         if not mode and split_input:
             mode = self.planes_mode(doctree, d)
             if mode:
                 x = ops.planes_split(x, mode)
+        if not mode and self.in_channels < 32:
+            # the network's input convolution (3 or 8 channels): zero-pad the channels to one 32 (64)-wide chunk and
+            # run the planes kernel on it -- 9 k tiles instead of materialising the reference's col rows for a
+            # dense GEMM (graph_unet_hr.py:116, modules.py:199-213)
+            mode = self.planes_mode(doctree, d, cin=32)
+            if mode:
+                cin_k = 32 if mode == 2 else 64
+                x = ops.planes_split(x, mode, Cpad=cin_k)
         if mode:
-            pw2 = self._pw2.get(self.weights, self.in_channels, nt, mode)
-            y = ops.graphconv_planes(x, mode, seg_ptr, col, doctree.ext(d), pw2, self.in_channels, nt,
+            pw2 = self._pw2.get(self.weights, self.in_channels, nt, mode, cin_pad=cin_k)
+            y = ops.graphconv_planes(x, mode, seg_ptr, col, doctree.ext(d), pw2, cin_k, nt,
                                      doctree.type_frac_planes(d, nt, mode) if nt else None,
                                      self.bias if self.use_bias else None, emb,
                                      doctree.batch_id32(d) if (emb is not None or stats is not None) else None,

@@ -128,8 +128,10 @@ class PackedPlanes:
         self.t = None
         self.key = None
 
-    def get(self, w, cin, nt, mode):
-        key = (w.data_ptr(), w._version, tuple(w.shape), cin, nt, mode)
+    def get(self, w, cin, nt, mode, cin_pad=None):
+        """cin_pad > cin: the layer's input is zero-padded to cin_pad channels (weights get zero rows)."""
+        cin_pad = cin if cin_pad is None else cin_pad
+        key = (w.data_ptr(), w._version, tuple(w.shape), cin, nt, mode, cin_pad)
         if key == self.key:
             return self
         _chk(w)
@@ -137,11 +139,20 @@ class PackedPlanes:
         if not w.is_contiguous():
             w = w.contiguous()
         K, N = w.shape
-        assert K == 7 * (cin + (nt if nt > 1 else 0))
+        ntc = nt if nt > 1 else 0
+        assert K == 7 * (cin + ntc)
+        k_logical, cin_logical = K, cin                      # what the algorithmic flop / byte counts use
+        if cin_pad != cin:
+            wp = torch.zeros(7, cin_pad + ntc, N, dtype=torch.float32, device=w.device)
+            w3 = w.view(7, cin + ntc, N)
+            wp[:, :cin] = w3[:, :cin]
+            wp[:, cin_pad:] = w3[:, cin:]
+            w = wp.view(7 * (cin_pad + ntc), N)
+            cin, K = cin_pad, 7 * (cin_pad + ntc)
         L = _lib.lib()
         out = torch.empty(L.ofx_planes_packed_bytes(cin, nt, N, mode), dtype=torch.uint8, device=w.device)
         call('ofx_pack_weights_planes', ptr(w), N, 1, cin, nt, N, mode, ptr(out), stream())
-        self.t, self.key, self.N, self.K, self.cin, self.nt = out, key, N, K, cin, nt
+        self.t, self.key, self.N, self.K, self.cin, self.nt = out, key, N, k_logical, cin_logical, nt
         self.nkt = L.ofx_planes_packed_ktiles(cin, nt, mode)
         return self
 
@@ -188,8 +199,8 @@ def graphconv_planes(xp, mode, seg_ptr, col, ext, pw, cin, nt, tf_planes=None, b
         E = col.numel()
         s_in = 4.0 if mode == 2 else 2.0
         flops = 2.0 * N * pw.K * pw.N
-        nbytes = s_in * (E * cin + pw.K * pw.N) + 4.0 * N * pw.N + 8.0 * E
-        prof.append((e0, e1, flops, nbytes, pw.N, ('graph2' if mode == 2 else 'graph2h', N, cin, pw.N)))
+        nbytes = s_in * (E * pw.cin + pw.K * pw.N) + 4.0 * N * pw.N + 8.0 * E
+        prof.append((e0, e1, flops, nbytes, pw.N, ('graph2' if mode == 2 else 'graph2h', N, pw.cin, pw.N)))
     return out
 
 

@@ -222,6 +222,35 @@ def cpu_baseline(name, batch):
                             'hr step in round 1); 32 threads is the fastest setting found' % ncpu}
 
 
+def parity_spot_check(wl, dev):
+    """One FULL-SIZE layer of the benchmarked net on the benchmark's own tree against the CPU oracle: the first
+    res-block's conv1 (GroupNorm + SiLU -> GraphConv 128 -> 128 at the input depth, the planes kernel's path)."""
+    from octfusion_amd import synthetic
+    from oracle import dual_octree as OD, modules as OM, sampler as OS
+    net = getattr(wl.net, 'unet_' + wl.stage)
+    blk = net.input_blocks[1]
+    d = net.input_depth
+    split = synthetic.shell6_split(wl.batch, jitter=True)
+    oc = OS.split2octree_small(split, 6, 4)
+    if wl.w['tree'] == 'shell8':
+        x6, y6, z6, _ = oc.xyzb(6)
+        oc = OS.split2octree_large(oc, synthetic.shell8_split_large(x6, y6, z6), 6)
+    o_doc = OD.OracleDualOctree(oc)
+    o_doc.post_processing_for_docnn()
+    C = blk.channels
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(wl.doc.csr(d)[2], C, generator=g)
+    sd = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    h_ref = OM.silu(OM.dual_octree_group_norm(x, o_doc, d, sd['block1_norm.weights'], sd['block1_norm.bias']))
+    y_ref = OM.graph_conv(h_ref, o_doc, d, sd['conv1.weights'], None, blk.conv1.n_node_type)
+    h = blk.block1_norm(x.to(dev), wl.doc, d, act='silu', planes=blk.conv1.planes_mode(wl.doc, d))
+    y = blk.conv1(h, wl.doc, d).cpu()
+    err = float((y - y_ref).abs().max() / y_ref.abs().max())
+    return {'layer': 'input_blocks.1: GroupNorm+SiLU -> GraphConv %d -> %d at depth %d, N = %d' % (
+        C, blk.out_channels, d, x.shape[0]), 'planes_kernel': bool(getattr(h, '_ofx_planes', 0)),
+        'rel_to_max_vs_oracle': err, 'bound': 1e-3}
+
+
 def gather_microbench(doc, dev, C=128, iters=20):
     """Stand-alone segment-mean gather (the reference's col_data) at depth 6: HBM GB/s."""
     from octfusion_amd import ops
@@ -396,8 +425,6 @@ def main():
         ops.GRAPHCONV_PROFILE = None
         eager_ms = 1e3 * dt_prof / K
 
-    # ---- parity spot check instead of an isfinite assert: one full-size GraphConv output row block against the
-    # exact-fp32 MFMA kernel (the oracle itself is checked in tests/; here the product checks its own fast path)
     assert bool(torch.isfinite(wl.x).all())
 
     res = None
@@ -406,7 +433,7 @@ def main():
         peak = {'bf16x3': MFMA_16BIT_PEAK_TFLOPS / 3.0, 'fp32': MFMA_F32_PEAK_TFLOPS, 'fp16': MFMA_16BIT_PEAK_TFLOPS}[bf]
         planes_kind = {'bf16x3': 'graph2', 'fp16': 'graph2h'}.get(bf)
         dom = profile_summary(prof, dt_prof, (planes_kind,), peak) if planes_kind else None
-        dom_name = ('gconv2_kernel<%d,1> (fused GraphConv on operand planes: LDS-DMA gather -> %s MFMA, fp32 accumulate)'
+        dom_name = ('gconv2_kernel<%d,5,*,*> (fused GraphConv on operand planes: LDS-DMA gather -> %s MFMA, fp32 accumulate)'
                     % ((2, 'bf16x3') if bf == 'bf16x3' else (1, 'fp16')))
         if dom is None:         # exact-fp32 mode / dense lr stage: the register-staged kernel carries the time
             dom = profile_summary(prof, dt_prof, ('graph', 'grid'), peak)
@@ -518,6 +545,9 @@ def main():
         if wl.doc is not None and 6 in wl.doc._csr:
             res['gather'] = gather_microbench(wl.doc, dev)
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        if wl.doc is not None:
+            res['parity_spot_check'] = parity_spot_check(wl, dev)
+            assert res['parity_spot_check']['rel_to_max_vs_oracle'] < 1e-3, res['parity_spot_check']
         res['cpu_baseline'] = cpu_baseline(args.workload, batch)
         res['gpu_over_cpu'] = res['value'] / res['cpu_baseline']['value']
     if rank == 0:

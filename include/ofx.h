@@ -326,7 +326,9 @@ int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int cin, int64_t
                              const float* bias, const float* emb, int64_t lde, const int32_t* batch_id,
                              const float* res, int64_t ldr, float* out, int64_t ldc, double* stats /* optional */,
                              int64_t stats_ld, void* ws, size_t ws_bytes, int mode, int aux_ready, void* stream);
-/* scheduling variant of the planes kernel (0: DMA requests before the MFMA group, 1: interleaved) -- A/B knob */
+/* scheduling variant of the planes kernel: 5 (default) = LDS reads and DMA requests spliced between the MFMAs,
+ * 1 = DMA requests interleaved by the compiler's sched_group_barrier, 0 = requests before the MFMA group;
+ * 2, 3, 4, 6 = timing ablations with WRONG results (no MFMA / no DMA / no fragment reads / no barrier) -- A/B knob */
 int ofx_set_gconv2_variant(int v);
 /* block geometry of the planes kernel: 0 = automatic, 2 = 128 x 128 tiles (4 waves, two blocks per CU),
  * 4 = 256 x 128 tiles (8 waves, one block per CU) -- A/B knob */

@@ -1,23 +1,21 @@
-// libofx: fp32-MFMA contraction core: dense GEMM, the fused dual-octree GraphConv and the
-// dense-grid 3x3x3 convolution (same kernel, 27 "directions").
+// libofx: register-staged contraction core (round 1): dense GEMM, the fused dual-octree GraphConv for the layers the
+// planes kernel (ofx_gemm2.hip) does not take, and the dense-grid 3x3x3 convolution (same kernel, 27 "directions").
 //
-// One kernel template, two A-tile loaders:
+// One kernel template per contraction precision, two A-tile loaders:
 //   MODE_DENSE  : A[arow(m), k] row-major (optional row map)                 -> ofx_gemm_f32
 //   MODE_GATHER : A[m, dir*cin + c] = x[nbr[m, dir], c]  (segment mean when a (row,dir)
 //                 has several neighbours), then the dense node-type-fraction slab
 //                                                      -> ofx_graphconv_fwd / ofx_gridconv_fwd
 // The gathered [N, ndir*cin] "col_data" of the reference (modules.py:208-210) never exists
 // in HBM: neighbour rows are fetched (16 B per lane, one 128-B line per 8 lanes) straight
-// into the LDS A-tile.  Neighbour indices are read once per (row, direction) -- not once per
-// k-tile -- and prefetched one direction ahead, so the k-loop carries no dependent loads.
+// into the LDS A-tile.
 //
-// Tiling (wave = 64): block = 4 waves, BM = 128 rows, BK = 32; BN = 128 (2x2 waves of 64x64),
-// 64 (2x2 of 64x32) or 32 (4x1 of 32x32).  Matrix core: v_mfma_f32_32x32x2_f32 -- exact fp32
-// (k-ordered fma chain), 157 TF peak on gfx950; parity with the fp32 reference is by
-// construction.  LDS: A tile [128][32+4] fp32 (pad 4 -> conflict-free ds_read_b128 over the
-// 16-lane groups), B tile [8][BN][4] read as one ds_read_b128 per 4 k-steps; double buffered,
-// one barrier per k-tile.  Weights are pre-packed once (ofx_pack_weights / ofx_pack_conv3d)
-// to [k/4][n][4] so the B tile is a straight 16-B-per-lane copy.
+// Precisions (ofx_set_precision): 0 (default) = bf16x3: both operands split into bf16 hi + lo, three
+// v_mfma_f32_32x32x16_bf16 per product term, fp32 accumulate (gemm_bf16x3_kernel; ~1e-5 of an fp32 reference);
+// 1 = exact fp32: v_mfma_f32_32x32x2_f32, a k-ordered fma chain (gemm_fast_kernel / gemm_kernel; 157 TF peak).
+// Tiling (wave = 64): block = 4 waves, BM = 128 rows, BK = 32; BN = 128 (2x2 waves of 64x64), 64 (2x2 of 64x32) or
+// 32 (4x1 of 32x32).  Weights are pre-packed once (ofx_pack_weights / ofx_pack_conv3d): fp32 [k/4][n][4] followed by
+// the bf16 hi | lo planes [k/8][n][8].
 // Small-M problems (dense 4^3 / 8^3 grids) are split along K into up to 64 slices whose
 // partial tiles go to a workspace and are summed, in slice order (deterministic), by
 // splitk_reduce_kernel, which also applies the epilogue.

@@ -26,6 +26,7 @@
 // (operands rounded to fp16: ~5e-4 per product, reduced-precision mode for BASELINE configs[4]).
 // The epilogue (bias / time-embedding / residual / fused GroupNorm statistics) is shared with ofx_gemm.hip.
 #include <type_traits>
+#include <utility>
 
 #include "ofx_gemm_common.h"
 
@@ -73,6 +74,7 @@ struct Gemm2Args {
   int tpd, nkt_g, nkt;                    // k tiles per direction, gather tiles (7 * tpd), all tiles
   unsigned long long* dbg;                // optional [blocks][8] shader-clock stamps (ofx_set_gconv2_debug)
   int stagger;                            // shader clocks the second block of each CU waits before its first tile (WM 2)
+  int64_t row0;                           // first output row of this launch (bulk + remainder launches split the rows)
   GemmArgs e;                             // M, N, epilogue operands, tile grid
 };
 
@@ -80,6 +82,16 @@ __device__ __forceinline__ unsigned long long g2_clock() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
   return t;
+}
+
+// compile-time unrolled loop: f(std::integral_constant<int, 0>()), ..., f(std::integral_constant<int, N - 1>())
+template <typename F, int... Is>
+__device__ __forceinline__ void g2_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>()), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void g2_static_for(F&& f) {
+  g2_static_for_impl(f, std::make_integer_sequence<int, N>());
 }
 
 template <int PREC> struct G2Frag;
@@ -127,15 +139,23 @@ __device__ __forceinline__ void g2_wait_lgkm(G2Half<PREC, 1>& F) {
 }
 // wait for all but the newest VM DMA instructions of this wave and for ALL its LDS reads (guarding F), then meet
 // the block.  The memory clobber keeps DMA issues and LDS traffic on their side of the barrier.
-template <int VM, int PREC>
+template <int VM, int PREC, bool BAR = true>
 __device__ __forceinline__ void g2_wait_barrier(G2Half<PREC, 2>& F) {
+  if (!BAR) {                  // ablation only: the waits without the block-wide rendezvous
+    asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)"
+                 : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[0][1]),
+                   "+v"(F.b[1][0]), "+v"(F.b[1][1])
+                 : "n"(VM)
+                 : "memory");
+    return;
+  }
   asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)\n\ts_barrier"
                : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[0][1]),
                  "+v"(F.b[1][0]), "+v"(F.b[1][1])
                : "n"(VM)
                : "memory");
 }
-template <int VM, int PREC>
+template <int VM, int PREC, bool BAR = true>
 __device__ __forceinline__ void g2_wait_barrier(G2Half<PREC, 1>& F) {
   asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)\n\ts_barrier"
                : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[1][0])
@@ -347,7 +367,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
   const int tm = bid / g.ntn, tn = bid - tm * g.ntn;
-  const int64_t m0 = (int64_t)tm * G2_BM, n0 = (int64_t)tn * G2_BN;
+  const int64_t m0 = a.row0 + (int64_t)tm * G2_BM, n0 = (int64_t)tn * G2_BN;
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -427,7 +447,8 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
     for (int j = 0; j < BPW; ++j) {
       int64_t c = n0 + wid * (8 * BPW) + j * 8 + rsub;
       c = c < Nc ? c : Nc - 1;
-      wb[j] = (gcp)a.W2 + c * G2_LINE + ((j & 1) ? pa1 : pa0);
+      const int brow = wid * (8 * BPW) + j * 8 + rsub;                 // row of this line in the staged weight tile
+      wb[j] = (gcp)a.W2 + c * G2_LINE + (q8 ^ ((brow >> 1) & 7)) * 16;   // source-side swizzle, as for the A rows
     }
   }
 
@@ -503,6 +524,20 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
     }
   };
 
+  // single LDS read r (0 .. RH-1) of half c: the order read_half issues them in
+  auto read_one = [&](int ob, int c, Half& F, auto r_tag) {
+    constexpr int r = decltype(r_tag)::value;
+    constexpr int NA = 2 * G2_MI;                    // A reads first: (u, i) = (r / MI, r % MI)
+    if constexpr (r < NA) {
+      constexpr int u = r / G2_MI, i = r % G2_MI;
+      if constexpr (i == 0) g2_ds_read128<0>(F.a[u][0], fa[c][u] + ob);
+      else g2_ds_read128<32 * G2_LINE>(F.a[u][1], fa[c][u] + ob);
+    } else {
+      constexpr int q = r - NA, u = q / G2_NI, j = q % G2_NI;
+      if constexpr (j == 0) g2_ds_read128<0>(F.b[u][0], fb[c][u] + ob);
+      else g2_ds_read128<32 * G2_LINE>(F.b[u][1], fb[c][u] + ob);
+    }
+  };
   f32x16 acc[G2_MI][G2_NI];
 #pragma unroll
   for (int i = 0; i < G2_MI; ++i)
@@ -541,9 +576,71 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
   };
 
 #define G2_FENCE() __builtin_amdgcn_sched_barrier(0)
-  // ---- prologue: tiles 0 and 1 in flight, tile 0 landed for everyone, its first half on its way to registers
   Half F0, F1;
   G2Idx I;
+  // single MFMA m of a half (same order as mfma_half)
+  auto mfma_one = [&](const Half& F, auto m_tag) {
+    constexpr int m = decltype(m_tag)::value;
+    constexpr int per = G2_MI * G2_NI, t = m / per, i = (m / G2_NI) % G2_MI, j = m % G2_NI;
+    if constexpr (PREC == 2) {
+      if constexpr (t == 0) acc[i][j] = g2_mfma<PREC>(F.a[1][i], F.b[0][j], acc[i][j]);
+      else if constexpr (t == 1) acc[i][j] = g2_mfma<PREC>(F.a[0][i], F.b[1][j], acc[i][j]);
+      else acc[i][j] = g2_mfma<PREC>(F.a[0][i], F.b[0][j], acc[i][j]);
+    } else {
+      acc[i][j] = g2_mfma<PREC>(F.a[t][i], F.b[t][j], acc[i][j]);
+    }
+  };
+  // DMA instruction k (0 .. GLDS-1) of a tile request: k < 4 -> A rows, else weight lines
+  auto issue_one = [&](const Tile& T, int ob, const G2Idx& I, auto k_tag) {
+    constexpr int k = decltype(k_tag)::value;
+    if constexpr (k < 4) {
+      const gcp b = T.base + ((k & 1) ? pa1 : pa0);
+      __builtin_amdgcn_global_load_lds(b + ((uint64_t)I.v[k] << 7),
+                                       (ldsp)(smem2 + ob + wid * (32 * G2_LINE) + k * (8 * G2_LINE)), 16, 0, 0);
+    } else {
+      constexpr int j = k - 4;
+      __builtin_amdgcn_global_load_lds(wb[j] + (int64_t)T.ktw * wstep,
+                                       (ldsp)(smem2 + ob + G2_A_BYTES + wid * (8 * BPW * G2_LINE) + j * (8 * G2_LINE)),
+                                       16, 0, 0);
+    }
+  };
+  constexpr int NMF = (PREC == 2 ? 3 : 2) * G2_MI * G2_NI;           // MFMAs per half step
+  // MFMAs of half Fc with (a) the LDS reads of the NEXT half set Fr (from stage ob_r, half c_r) and (b) optionally the
+  // DMA request of tile T spliced between them, in a pinned order: the reads / requests issue in the shadow of the
+  // matrix pipe instead of in front of it (variant 5; the un-spliced order leaves the pipe idle while a wave issues
+  // its 8-12 LDS reads after every barrier and at every step start)
+  auto mfma_spliced = [&](const Half& Fc, bool do_read, int ob_r, int c_r, Half& Fr, auto dma_tag, const Tile& T,
+                          int ob_dma) {
+    constexpr bool DMA = decltype(dma_tag)::value;
+    auto body = [&](auto m_tag) {
+      constexpr int m = decltype(m_tag)::value;
+      mfma_one(Fc, m_tag);
+      if constexpr (m < RH) {
+        if (do_read) read_one(ob_r, c_r, Fr, m_tag);
+      }
+      if constexpr (DMA) {
+        if constexpr (m == 1) g2_wait_lgkm<(RH < 2 ? RH : 2)>(I);        // table entries: 2 younger reads so far
+        if constexpr (m >= 2 && m - 2 < G2_GLDS_PER_STEP) issue_one(T, ob_dma, I, std::integral_constant<int, m - 2>());
+      }
+      G2_FENCE();
+    };
+    g2_static_for<NMF>(body);
+    if constexpr (RH > NMF) {                                             // reads that did not fit (fp16, 64-column tile)
+      g2_static_for<RH>([&](auto r_tag) {
+        constexpr int r = decltype(r_tag)::value;
+        if constexpr (r >= NMF) {
+          if (do_read) read_one(ob_r, c_r, Fr, r_tag);
+        }
+      });
+    }
+    if constexpr (DMA) {                                                  // requests that did not fit between the MFMAs
+      g2_static_for<G2_GLDS_PER_STEP>([&](auto k_tag) {
+        constexpr int k = decltype(k_tag)::value;
+        if constexpr (k + 2 >= NMF) issue_one(T, ob_dma, I, k_tag);
+      });
+    }
+  };
+  // ---- prologue: tiles 0 and 1 in flight, tile 0 landed for everyone, its first half on its way to registers
   {
     const Tile T0 = tile_of(0);
     load_idx(T0, I);
@@ -585,7 +682,37 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
   };
   auto step_issue = [&](const Tile& T, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
-    if constexpr (CF::NBUF == 3) {
+    if constexpr ((VARIANT == 5 || VARIANT == 6) && CF::NBUF == 3) {
+      // spliced schedule, 3 stages: table reads | wait F0 (4 younger) | {MFMA F0, read F1, request tile it+2} |
+      // barrier | {MFMA F1, read F0 of tile it+1}
+      load_idx(T, I);
+      g2_wait_lgkm<4, PREC>(F0);
+      G2_FENCE();
+      if (LAST) {
+        g2_epilogue_request<G2_WM, G2_WN, G2_MI, G2_NI>(g, (const void*)a.W2, P, m0, n0, wm, wn, l31, h);
+        G2_FENCE();
+      }
+      mfma_spliced(F0, true, ob, 1, F1, std::true_type(), T, obnn);
+      g2_wait_barrier<G2_GLDS_PER_STEP + (LAST ? G2_EPI_LOADS : 0), PREC, VARIANT != 6>(F1);
+      G2_FENCE();
+      mfma_spliced(F1, true, obn, 0, F0, std::false_type(), T, 0);
+      const int t = ob; ob = obn; obn = obnn; obnn = t;
+    } else if constexpr (VARIANT == 5 || VARIANT == 6) {
+      // spliced schedule, 2 stages: wait F0 | {MFMA F0, read F1} | barrier | table reads | {MFMA F1, read F0 of tile
+      // it+1, request tile it+2 into the buffer tile it just left}
+      g2_wait_lgkm<0, PREC>(F0);
+      G2_FENCE();
+      if (LAST) {
+        g2_epilogue_request<G2_WM, G2_WN, G2_MI, G2_NI>(g, (const void*)a.W2, P, m0, n0, wm, wn, l31, h);
+        G2_FENCE();
+      }
+      mfma_spliced(F0, true, ob, 1, F1, std::false_type(), T, 0);
+      g2_wait_barrier<(LAST ? G2_EPI_LOADS : 0), PREC>(F1);
+      G2_FENCE();
+      load_idx(T, I);
+      mfma_spliced(F1, true, obn, 0, F0, std::true_type(), T, ob);
+      const int t = ob; ob = obn; obn = t;
+    } else if constexpr (CF::NBUF == 3) {
       // 3 stages: tile it+2 is requested in the FIRST half of step it (its buffer was left at step it-1)
       load_idx(T, I);
       read_half(ob, 1, F1);
@@ -657,6 +784,15 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
     ++it;
   }
   for (; it < nkt; ++it) {                       // last two tiles: nothing left to request
+    if constexpr (VARIANT == 5 || VARIANT == 6) {
+      Tile Tn = {};
+      g2_wait_lgkm<0, PREC>(F0);
+      G2_FENCE();
+      mfma_spliced(F0, true, ob, 1, F1, std::false_type(), Tn, 0);
+      g2_wait_barrier<0, PREC>(F1);
+      G2_FENCE();
+      mfma_spliced(F1, it + 1 < nkt, obn, 0, F0, std::false_type(), Tn, 0);
+    } else {
     read_half(ob, 1, F1);
     g2_wait_lgkm<RH, PREC>(F0);
     G2_FENCE();
@@ -668,6 +804,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
     G2_FENCE();
     mfma_half(F1);
     G2_FENCE();
+    }
     if (CF::NBUF == 3) {
       const int t = ob; ob = obn; obn = obnn; obnn = t;
     } else {
@@ -904,9 +1041,9 @@ extern "C" int ofx_pack_weights_planes(const float* W, int64_t sk, int64_t sn, i
 // ------------------------------------------------------------------------------------------------
 int ofx_launch_stats_reduce(const GemmArgs& g, int wr_rows, hipStream_t st);   // ofx_gemm.hip
 
-static int g2_variant = 1;
+static int g2_variant = 5;     // 5 = spliced schedule (product); 1 / 0 = earlier schedules, 2-4 / 6 = ablations
 extern "C" int ofx_set_gconv2_variant(int v) {
-  if (v < 0 || v > 4) return OFX_EINVAL;
+  if (v < 0 || v > 6) return OFX_EINVAL;
   g2_variant = v;
   return OFX_OK;
 }
@@ -979,12 +1116,6 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
     g.vec4 = g.N % 4 == 0 && al16(g.out) && g.ldc % 4 == 0 && (!g.res || (al16(g.res) && g.ldr % 4 == 0)) &&
              (!g.emb || (al16(g.emb) && g.lde % 4 == 0)) && (!g.bias || al16(g.bias));
   }
-  // geometry: one output-column tile (cout <= 128) -> 128-row tiles, two staggered blocks per CU (measured 3-9 %
-  // faster: prologue / epilogue overlap); several column tiles -> 256-row tiles, whose larger weight-tile reuse wins
-  // (cout 256 / 512 layers 5-15 % faster) -- profiles/r02/gconv2_geometry.txt
-  const int wm = g2_wm ? g2_wm : (cout <= 128 ? 2 : 4);
-  a.stagger = g2_stagger_per_ktile * a.nkt;
-  g.ntm = (int)ofx_cdiv(g.M, wm * 64);
   const int ni = cout <= 64 ? 1 : 2;              // 64-column tiles for the narrow layers
   g.ntn = (int)ofx_cdiv(g.N, 64 * ni);
   if (stats) {
@@ -994,21 +1125,35 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
       g.stats_part = (float*)ws; g.stats_part_bytes = ws_bytes;
     }
   }
-  int rc;
-#define G2_GO(P_, V_)                                                                               \
-  (ni == 1 ? (wm == 4 ? g2_launch<P_, V_, 4, 1>(a, st) : g2_launch<P_, V_, 2, 1>(a, st))             \
-           : (wm == 4 ? g2_launch<P_, V_, 4, 2>(a, st) : g2_launch<P_, V_, 2, 2>(a, st)))
-  if (mode == 2) {
-    switch (g2_variant) {
-      case 0: rc = G2_GO(2, 0); break;
-      case 2: rc = G2_GO(2, 2); break;      // ablations (wrong results): no MFMA / no DMA / no LDS reads
-      case 3: rc = G2_GO(2, 3); break;
-      case 4: rc = G2_GO(2, 4); break;
-      default: rc = G2_GO(2, 1); break;
+  // ---- geometry: one output-column tile (cout <= 128) -> 128-row tiles, two staggered blocks per CU (prologue /
+  // epilogue overlap, +3-9 %); several column tiles -> 256-row tiles (larger weight-tile reuse, cout 256 / 512 layers
+  // +5-15 %).  Splitting the rows into a bulk launch of whole "rounds" of 256-row tiles plus a remainder launch of
+  // 128-row tiles (against tile quantisation: 530 tiles on 256 CUs = 2.07 rounds) was built and measured: no gain
+  // (blocks do not run in lock-step rounds, and the second launch pays its own fill and drain) --
+  // profiles/r02/gconv2_geometry.txt.
+  int rc = OFX_OK;
+#define G2_GO(P_, V_, WM_)                                                                            \
+  (ni == 1 ? (WM_ == 4 ? g2_launch<P_, V_, 4, 1>(a, st) : g2_launch<P_, V_, 2, 1>(a, st))             \
+           : (WM_ == 4 ? g2_launch<P_, V_, 4, 2>(a, st) : g2_launch<P_, V_, 2, 2>(a, st)))
+  auto launch = [&](int wm, int64_t row0, int64_t rows) -> int {
+    a.row0 = row0;
+    g.ntm = (int)ofx_cdiv(rows, wm * 64);
+    a.stagger = wm == 2 ? g2_stagger_per_ktile * a.nkt : 0;
+    if (mode == 2) {
+      switch (g2_variant) {
+        case 0: return G2_GO(2, 0, wm);
+        case 2: return G2_GO(2, 2, wm);      // ablations (wrong results): no MFMA / no DMA / no LDS reads
+        case 3: return G2_GO(2, 3, wm);
+        case 4: return G2_GO(2, 4, wm);
+        case 5: return G2_GO(2, 5, wm);      // spliced schedule (reads / requests between the MFMAs)
+        case 6: return G2_GO(2, 6, wm);      // ablation: spliced schedule without the per-step s_barrier (races)
+        case 1: return G2_GO(2, 1, wm);
+        default: return G2_GO(2, 5, wm);
+      }
     }
-  } else {
-    rc = g2_variant == 0 ? G2_GO(1, 0) : G2_GO(1, 1);
-  }
+    return g2_variant == 0 ? G2_GO(1, 0, wm) : (g2_variant == 1 ? G2_GO(1, 1, wm) : G2_GO(1, 5, wm));
+  };
+  rc = launch(g2_wm ? g2_wm : (cout <= 128 ? 2 : 4), 0, g.M);
 #undef G2_GO
   if (rc) return rc;
   if (g.stats_part) {

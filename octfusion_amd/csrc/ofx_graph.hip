@@ -10,7 +10,8 @@
 // itself is a coarser leaf) is expanded into its face-touching descendants.
 // Emitting per (row, dir) yields the reference's sorted-by-row*7+dir order with no
 // sort, and CSR segments come for free.  Output is bit-identical to the reference
-// after canonical (row, dir, col) ordering (tests/test_graph_parity.py).
+// after canonical (row, dir, col) ordering (tests/test_gpu_parity.py: test_octree_and_graph_*,
+// test_graph_vs_oracle_random, test_full_size_shell6_b8_properties).
 #include "ofx_common.h"
 
 struct TreeDev {

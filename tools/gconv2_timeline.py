@@ -15,7 +15,7 @@ torch.set_grad_enabled(False)
 doc = DualOctree(split2octree_small(synthetic.shell6_split(8).to(dev), 6, 4))
 ops.PLANES_MIN_TILES = 1
 import itertools
-VARIANTS = [int(v) for v in os.environ.get("G2_VARIANTS", "1").split(",")]
+VARIANTS = [int(v) for v in os.environ.get("G2_VARIANTS", "5").split(",")]
 TILES = [int(v) for v in os.environ.get("G2_TILES", "2,4").split(",")]
 for (d, cin, cout, epi), variant, tile in itertools.product([(6, 128, 128, True), (6, 128, 128, False), (6, 384, 128, True), (5, 256, 256, True)], VARIANTS, TILES):
     _lib.call("ofx_set_gconv2_variant", variant)

@@ -26,7 +26,7 @@ for d, cin, cout in [(6, 128, 128), (6, 384, 128), (6, 256, 256), (5, 256, 256),
     emb = torch.randn(8, cout, device=dev)
     ref, row = None, []
     for tile in (4, 2):
-        for variant in (1, 5):
+        for variant in [int(v) for v in os.environ.get('G2_VARIANTS', '1,5').split(',')]:
             _lib.call('ofx_set_gconv2_tile', tile)
             _lib.call('ofx_set_gconv2_variant', variant)
             y = conv(xp, doc, d, emb=emb, res=res)

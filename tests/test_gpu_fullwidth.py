@@ -239,3 +239,88 @@ def test_per_layer_sweep():
                         planes_kernel=planes, **e))
             assert e['rel_to_max'] < (2e-4 if prec != 'fp16' else 5e-3), (d, cin, cout, prec, planes, e)
     report(dict(test='layer_sweep_worst', shapes=len(shapes), **{'%s_%s' % k: v for k, v in worst.items()}))
+
+
+@pytest.mark.parametrize('prec', ['bf16x3', 'fp16'])
+def test_planes_kernel_edge_cases(prec):
+    """The LDS-DMA planes GraphConv off the beaten path: ragged batch of 5 with an element that has nothing below the
+    full layer (tile / wave boundaries fall inside batch elements: mixed-batch statistics), output widths that are
+    not multiples of the 128 / 64-column tiles (200, 72, 64, 132) incl. the clamped-column path, every block geometry
+    (128 / 256 rows), bias + time-embedding + residual + fused GroupNorm statistics, planes written by the GroupNorm
+    (with the folded aux rows) vs by ofx_planes_split (+ stand-alone pre-pass), M = a handful of rows.  Against the
+    oracle in fp64 (modules.py:194-220, 291-314)."""
+    from octfusion_amd import _lib, modules as M, ops
+    from octfusion_amd.dual_octree import DualOctree
+    from octfusion_amd.octree import split2octree_small
+    from oracle import dual_octree as OD, modules as OM, sampler as OS
+    mode = 2 if prec == 'bf16x3' else 1
+    tol = 2e-4 if prec == 'bf16x3' else 5e-3
+    split = C.random_split_small(5, 3, 41, p=0.4)
+    split[3] = -1.0
+    doc = DualOctree(split2octree_small(split.to(dev()), 5, 3))
+    o_doc = OD.OracleDualOctree(OS.split2octree_small(split, 5, 3))
+    o_doc.post_processing_for_docnn()
+    saved = (ops.get_precision(), ops.PLANES_MIN_TILES)
+    ops.set_precision(prec)
+    ops.PLANES_MIN_TILES = 1
+    try:
+        for d, cin, cout, nt, bias in [(5, 64, 200, 4, True), (5, 128, 72, 4, False), (4, 192, 64, 3, True),
+                                       (5, 64, 132, 0, False), (3, 64, 128, 2, True)]:
+            conv = M.GraphConv(cin, cout, 7, 7, nt, use_bias=bias)
+            gn = M.DualOctreeGroupNorm(cin)
+            sd = C.fill_state_dict([('c.' + k, tuple(v.shape)) for k, v in conv.state_dict().items()] +
+                                   [('g.' + k, tuple(v.shape)) for k, v in gn.state_dict().items()])
+            conv.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith('c.')})
+            gn.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith('g.')})
+            conv, gn = conv.to(dev()), gn.to(dev())
+            N = doc.csr(d)[2]
+            x = C.rand_input('edge_x_%d_%d' % (d, cin), N, cin)
+            emb = C.rand_input('edge_e_%d' % cout, 5, cout)
+            res = C.rand_input('edge_r_%d_%d' % (d, cout), N, cout)
+            h_ref = OM.silu(OM.dual_octree_group_norm(x.double(), o_doc, d, sd['g.weights'].double(), sd['g.bias'].double()))
+            ref = OM.graph_conv(h_ref, o_doc, d, sd['c.weights'].double(),
+                                sd['c.bias'].double() if bias else None, nt) + emb.double()[o_doc.batch_id(d)] + res.double()
+            outs = []
+            for tile in (2, 4):
+                _lib.call('ofx_set_gconv2_tile', tile)
+                # (a) planes + aux rows written by the GroupNorm launch
+                hp = gn(x.to(dev()), doc, d, act='silu', planes=mode)
+                assert ops.planes_of(hp) == mode and getattr(hp, ops.AUX_ATTR, None) is not None
+                with ops.stats_scope(dev()):
+                    conv.emit_stats = True
+                    stats = ops.stats_zeros(5 * cout * 2, dev()) if cout % 4 == 0 else None
+                    pw2 = conv._pw2.get(conv.weights, cin, nt if nt > 1 else 0, mode)
+                    seg_ptr, col, _, _ = doc.csr(d)
+                    y = ops.graphconv_planes(hp, mode, seg_ptr, col, doc.ext(d), pw2, cin, nt if nt > 1 else 0,
+                                             doc.type_frac_planes(d, nt, mode) if nt > 1 else None,
+                                             conv.bias if bias else None, emb.to(dev()), doc.batch_id32(d), res.to(dev()),
+                                             None, stats=stats)
+                    e = errors(y, ref)
+                    assert e['rel_to_max'] < tol, (d, cin, cout, tile, e)
+                    if stats is not None:
+                        bid = doc.batch_id32(d).long()
+                        want = torch.zeros(5, cout, 2, dtype=torch.float64, device=dev())
+                        want[:, :, 0].index_add_(0, bid, y.double())
+                        want[:, :, 1].index_add_(0, bid, y.double() ** 2)
+                        assert float((stats.view(5, cout, 2) - want).abs().max()) <= 1e-5 * float(want.abs().max())
+                # (b) the same activation converted by ofx_planes_split: stand-alone pre-pass instead of folded aux rows
+                hf = gn(x.to(dev()), doc, d, act='silu')
+                y2 = conv(ops.planes_split(hf, mode), doc, d, emb=emb.to(dev()), res=res.to(dev()))
+                assert errors(y2, ref)['rel_to_max'] < tol
+                outs.append(y)
+            assert torch.equal(outs[0], outs[1]), 'geometries disagree bit-wise'
+            report(dict(test='planes_edge', precision=prec, depth=d, N=N, cin=cin, cout=cout, nt=nt, **errors(outs[0], ref)))
+        # a graph level with a handful of rows (depth-3 full layer of ONE tiny tree: 512 rows < one 256-row tile x 2)
+        tiny = C.random_split_small(1, 2, 7, p=0.5)
+        doc1 = DualOctree(split2octree_small(tiny.to(dev()), 4, 2))
+        o1 = OD.OracleDualOctree(OS.split2octree_small(tiny, 4, 2))
+        o1.post_processing_for_docnn()
+        conv = M.GraphConv(64, 64, 7, 7, 2).to(dev())
+        x = C.rand_input('edge_tiny', doc1.csr(2)[2], 64)
+        ref = OM.graph_conv(x.double(), o1, 2, conv.weights.detach().cpu().double(), None, 2)
+        y = conv(x.to(dev()), doc1, 2, split_input=True)
+        assert errors(y, ref)['rel_to_max'] < tol
+    finally:
+        _lib.call('ofx_set_gconv2_tile', 0)
+        ops.set_precision(saved[0])
+        ops.PLANES_MIN_TILES = saved[1]

@@ -218,6 +218,33 @@ int ofx_mpu_eval(const ofx_tree_t* tree, int depth_start, int depth_end, const f
 int ofx_mpu_eval_grid(const ofx_tree_t* tree, int depth_start, int depth_end, const float* code, int size,
                       float step, float bbmin, int batch_index, int64_t head, int64_t count, float* sdf,
                       uint8_t* mask, void* stream);
+/* NeuralMPU with gradients (training): replaces compute_mpu_gradients (loss.py:100-108), i.e. autograd of
+ * get_linear_pred w.r.t. the query position with create_graph=True.  grad [n,3] = d sdf / d (x, y, z) with the
+ * reference's conventions (floor detached, d|f|/df = +1 at f = 0: mpu.py:18-32).  _backward is the adjoint of
+ * (sdf, grad) w.r.t. the code table: dcode [rows,4] += J^T (dsdf, dgrad) (fp32 atomics; the caller zeroes
+ * dcode; either upstream pointer may be NULL = zeros). */
+int ofx_mpu_eval_grad(const ofx_tree_t* tree, int depth_start, int depth_end, const float* pts, int64_t n_pts,
+                      const float* code, float* sdf, float* grad, uint8_t* mask, void* stream);
+int ofx_mpu_backward(const ofx_tree_t* tree, int depth_start, int depth_end, const float* pts, int64_t n_pts,
+                     const float* code, const float* dsdf, const float* dgrad, float* dcode, void* stream);
+/* VAE training losses, forward value + gradient w.r.t. the network output in one pass (loss.py:164-178).
+ * sums are fp64 accumulators the caller zeroes.
+ * _octree_ce (compute_octree_loss, loss.py:110-122): label = child[i] >= 0; sums[0] += sum of the 2-class cross
+ *   entropies, sums[1] += number of rows whose argmax equals the label; dlogits (optional) =
+ *   (softmax - onehot) * dscale (dscale = weight / n for the mean).
+ * _sdf_reg_loss (sdf_reg_loss, loss.py:23-29): sums[0] += sum (grad - grad_gt)^2 over 3n, sums[1] +=
+ *   sum (sdf - sdf_gt)^2; dsdf = 2 w_sdf (sdf - sdf_gt) / n, dgrad = 2 w_grad (grad - grad_gt) / (3n) (optional).
+ * _kl_sample (DiagonalGaussianDistribution, distributions.py:24-46): params [n, 2E] = (mean | logvar), logvar
+ *   clamped to [-30, 20]; z = mean + exp(logvar/2) * noise (noise NULL: the mean); kl_sum += sum of
+ *   0.5 (mean^2 + var - 1 - logvar).  _bwd: dparams = d/dparams of (<dz, z> + kl_scale * sum kl). */
+int ofx_octree_ce(const float* logits, int64_t ld, const int32_t* child, int64_t n, float dscale, double* sums,
+                  float* dlogits, int64_t ldd, void* stream);
+int ofx_sdf_reg_loss(const float* sdf, const float* grad, const float* sdf_gt, const float* grad_gt, int64_t n,
+                     float w_sdf, float w_grad, double* sums, float* dsdf, float* dgrad, void* stream);
+int ofx_kl_sample_fwd(const float* params, int64_t ld, const float* noise, int64_t n, int embed_dim, float* z,
+                      double* kl_sum, void* stream);
+int ofx_kl_sample_bwd(const float* params, int64_t ld, const float* noise, const float* dz, int64_t n,
+                      int embed_dim, float kl_scale, float* dparams, int64_t ldp, void* stream);
 /* Extended table for the branch-free kernel: flag[s] = segment s has > 1 neighbours;
  * with rank = exclusive scan of flag: nbr_ext[s] = neighbour id | N (none: zero row) |
  * N + 1 + rank[s] (several: pre-averaged row), multi_seg[rank[s]] = s. */

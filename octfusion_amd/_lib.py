@@ -71,6 +71,12 @@ _SIGS = {
     'ofx_gn_fused_rows': (c_i, [c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_i, c_p, c_l, c_p], True),
     'ofx_mpu_eval': (c_i, [ctypes.POINTER(OfxTree), c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p], True),
     'ofx_mpu_eval_grid': (c_i, [ctypes.POINTER(OfxTree), c_i, c_i, c_p, c_i, c_f, c_f, c_i, c_l, c_l, c_p, c_p, c_p], True),
+    'ofx_mpu_eval_grad': (c_i, [ctypes.POINTER(OfxTree), c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p], True),
+    'ofx_mpu_backward': (c_i, [ctypes.POINTER(OfxTree), c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p], True),
+    'ofx_octree_ce': (c_i, [c_p, c_l, c_p, c_l, c_f, c_p, c_p, c_l, c_p], True),
+    'ofx_sdf_reg_loss': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p, c_p], True),
+    'ofx_kl_sample_fwd': (c_i, [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p], True),
+    'ofx_kl_sample_bwd': (c_i, [c_p, c_l, c_p, c_p, c_l, c_i, c_f, c_p, c_l, c_p], True),
     'ofx_graph_fill': (c_i, [ctypes.POINTER(OfxTree), c_i, c_p, c_p, c_p], True),
     'ofx_graph_expand': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_p], True),
     'ofx_graph_type_frac': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_l, c_p], True),

@@ -537,6 +537,201 @@ extern "C" int ofx_mpu_eval_grid(const ofx_tree_t* tree, int depth_start, int de
 }
 
 // ---------------------------------------------------------------------------------
+// NeuralMPU with gradients -- the training-side use of the same field (reference loss.py:12-20, 100-108:
+// compute_mpu_gradients = autograd of get_linear_pred w.r.t. the query position, create_graph=True so the SDF
+// losses can be back-propagated into the per-node codes).  Everything autograd derives is written out:
+//   w_i = k_d prod_a (1 - |f_ia|),   v_i = c_i . (f_i s_d) + c_i3,   s_d = 2 / 2^d,   f = x 2^d/2 - 1/2 - centre
+//   num = sum w_i v_i,  den = sum w_i,  D = den + 1e-8,   sdf = num / D
+//   dw_ia = -sgn(f_ia) (2^d / 2) k_d prod_{b != a} (1 - |f_ib|)     (mpu.py:18-32: sgn(0) = +1; floor detached)
+//   dv_ia = c_ia                                                     (s_d * 2^d / 2 = 1 exactly)
+//   grad_a = (sum_i dw_ia v_i + w_i c_ia) / D - num (sum_i dw_ia) / D^2
+// and, given the upstream gradients a = dL/dsdf and b = dL/dgrad, the adjoint w.r.t. the codes (both outputs
+// are linear in c):   A_i = a w_i / D + sum_a b_a (dw_ia / D - w_i dden_a / D^2),
+//   dL/dc_ia = A_i f_ia s_d + b_a w_i / D,   dL/dc_i3 = A_i   (fp32 atomics into dcode).
+// Same eight-lanes-per-point walk as mpu_eval_kernel; the visitor is called once per depth by every lane.
+struct MpuVisit {
+  bool use;          // the centre exists (and is a leaf below depth_end)
+  bool found;
+  int64_t row;       // row of the code table
+  float fx, fy, fz;  // offset to the centre in cells
+  float wx, wy, wz;  // 1 - |f|
+  float kd, half, s; // d^2/50, 2^d / 2, 2 / 2^d
+};
+
+template <typename Fn>
+__device__ __forceinline__ void mpu_for_each(const TreeDev& T, int ds, int de, float px, float py, float pz, int b,
+                                             int corner, int lane_base, Fn&& fn) {
+  const int dx = (corner >> 2) & 1, dy = (corner >> 1) & 1, dz = corner & 1;
+  int64_t base_rows = 0;
+  int prev_idx = -1;
+  int pbx = 0, pby = 0, pbz = 0;
+  const bool bok = b >= 0 && b < T.batch_size;
+  for (int d = ds; d <= de; ++d) {
+    const int scale = 1 << d;
+    const float half = 0.5f * (float)scale;
+    const float x = (px + 1.0f) * half - 0.5f, y = (py + 1.0f) * half - 0.5f, z = (pz + 1.0f) * half - 0.5f;
+    const float bxf = floorf(x), byf = floorf(y), bzf = floorf(z);
+    const int bx = (int)bxf, by = (int)byf, bz = (int)bzf;
+    const int cx = bx + dx, cy = by + dy, cz = bz + dz;
+    MpuVisit v;
+    v.fx = x - (bxf + (float)dx); v.fy = y - (byf + (float)dy); v.fz = z - (bzf + (float)dz);
+    const bool inb = bok && cx >= 0 && cy >= 0 && cz >= 0 && cx < scale && cy < scale && cz < scale;
+    int idx = -1;
+    if (d == ds) {
+      if (inb) idx = (int)mpu_walk(T, d, cx, cy, cz, b);
+    } else {
+      const int pcx = (cx >> 1) - pbx, pcy = (cy >> 1) - pby, pcz = (cz >> 1) - pbz;
+      const bool pc_ok = (unsigned)pcx < 2u && (unsigned)pcy < 2u && (unsigned)pcz < 2u;
+      const int sl = (inb && pc_ok) ? ((pcx << 2) | (pcy << 1) | pcz) : 0;
+      const int pidx = __shfl(prev_idx, lane_base + sl);
+      if (inb && pc_ok) {
+        if (pidx >= 0) {
+          const int32_t c = T.child[T.ncum[d - 1] + pidx];
+          if (c >= 0) idx = c * 8 + (((cx & 1) << 2) | ((cy & 1) << 1) | (cz & 1));
+        }
+      } else if (inb) {
+        idx = (int)mpu_walk(T, d, cx, cy, cz, b);
+      }
+    }
+    v.found = idx >= 0;
+    v.use = v.found;
+    if (v.found && d < de) v.use = T.child[T.ncum[d] + idx] < 0;
+    v.row = base_rows + idx;
+    v.wx = 1.0f - fabsf(v.fx); v.wy = 1.0f - fabsf(v.fy); v.wz = 1.0f - fabsf(v.fz);
+    v.kd = (float)((double)(d * d) / 50.0);
+    v.half = half;
+    v.s = 2.0f / (float)scale;
+    fn(d, v);
+    prev_idx = idx;
+    pbx = bx; pby = by; pbz = bz;
+    base_rows += T.nnum[d];
+  }
+}
+
+struct MpuGradArgs {
+  TreeDev T;
+  int ds, de;
+  const float* pts;
+  int64_t n;
+  const float* code;
+  float* sdf;          // forward outputs
+  float* grad;         // [n, 3]
+  uint8_t* mask;
+  const float* dsdf;   // backward inputs (NULL: taken as 0)
+  const float* dgrad;  // [n, 3]
+  float* dcode;        // [rows, 4], accumulated with atomics
+};
+
+__device__ __forceinline__ float mpu_sgn(float f) { return f < 0.f ? -1.f : 1.f; }
+
+template <bool BACKWARD>
+__global__ void __launch_bounds__(256) mpu_grad_kernel(const MpuGradArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t q = t >> 3;
+  const int corner = (int)(t & 7);
+  const bool live = q < a.n;
+  const int64_t qc = live ? q : a.n - 1;
+  const float4 p = reinterpret_cast<const float4*>(a.pts)[qc];
+  const int b = (int)p.w;
+  const int lane_base = (int)(threadIdx.x & 63) & ~7;
+  float num = 0.f, den = 0.f, dn[3] = {0.f, 0.f, 0.f}, dd[3] = {0.f, 0.f, 0.f};
+  bool found_last = false;
+  mpu_for_each(a.T, a.ds, a.de, p.x, p.y, p.z, b, corner, lane_base, [&](int d, const MpuVisit& v) {
+    if (d == a.de) found_last = v.found;
+    if (!v.use) return;
+    const float4 c = reinterpret_cast<const float4*>(a.code)[v.row];
+    const float val = c.x * (v.fx * v.s) + c.y * (v.fy * v.s) + c.z * (v.fz * v.s) + c.w;
+    const float w = (v.wx * v.wy) * v.wz * v.kd;
+    const float hk = v.half * v.kd;
+    const float dwx = -mpu_sgn(v.fx) * hk * (v.wy * v.wz);
+    const float dwy = -mpu_sgn(v.fy) * hk * (v.wx * v.wz);
+    const float dwz = -mpu_sgn(v.fz) * hk * (v.wx * v.wy);
+    num += w * val; den += w;
+    dn[0] += dwx * val + w * c.x; dn[1] += dwy * val + w * c.y; dn[2] += dwz * val + w * c.z;
+    dd[0] += dwx; dd[1] += dwy; dd[2] += dwz;
+  });
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    num += __shfl_xor(num, o); den += __shfl_xor(den, o);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dn[k] += __shfl_xor(dn[k], o); dd[k] += __shfl_xor(dd[k], o); }
+  }
+  const float D = den + 1e-8f;
+  const float invD = 1.0f / D;
+  if (!BACKWARD) {
+    const unsigned long long bal = __ballot(found_last);
+    if (corner == 0 && live) {
+      a.sdf[q] = num * invD;
+      const float r = num * invD * invD;
+      a.grad[q * 3 + 0] = dn[0] * invD - r * dd[0];
+      a.grad[q * 3 + 1] = dn[1] * invD - r * dd[1];
+      a.grad[q * 3 + 2] = dn[2] * invD - r * dd[2];
+      if (a.mask) a.mask[q] = ((bal >> lane_base) & 0xffull) ? 1 : 0;
+    }
+    return;
+  }
+  const float up = (live && a.dsdf) ? a.dsdf[qc] : 0.f;
+  float bk[3] = {0.f, 0.f, 0.f};
+  if (live && a.dgrad) { bk[0] = a.dgrad[qc * 3]; bk[1] = a.dgrad[qc * 3 + 1]; bk[2] = a.dgrad[qc * 3 + 2]; }
+  // second walk: scatter the adjoint (every lane takes part in the shuffles of the walk)
+  mpu_for_each(a.T, a.ds, a.de, p.x, p.y, p.z, b, corner, lane_base, [&](int d, const MpuVisit& v) {
+    if (!v.use || !live) return;
+    const float w = (v.wx * v.wy) * v.wz * v.kd;
+    const float hk = v.half * v.kd;
+    const float dwx = -mpu_sgn(v.fx) * hk * (v.wy * v.wz);
+    const float dwy = -mpu_sgn(v.fy) * hk * (v.wx * v.wz);
+    const float dwz = -mpu_sgn(v.fz) * hk * (v.wx * v.wy);
+    const float wD = w * invD;
+    const float A = up * wD + bk[0] * (dwx - wD * dd[0]) * invD + bk[1] * (dwy - wD * dd[1]) * invD +
+                    bk[2] * (dwz - wD * dd[2]) * invD;
+    float* o = a.dcode + v.row * 4;
+    unsafeAtomicAdd(o + 0, A * (v.fx * v.s) + bk[0] * wD);
+    unsafeAtomicAdd(o + 1, A * (v.fy * v.s) + bk[1] * wD);
+    unsafeAtomicAdd(o + 2, A * (v.fz * v.s) + bk[2] * wD);
+    unsafeAtomicAdd(o + 3, A);
+  });
+}
+
+static int mpu_grad_check(const ofx_tree_t* tree, MpuGradArgs& a) {
+  int rc = make_tree(tree, a.T);
+  if (rc) return rc;
+  if (a.ds < 0 || a.de < a.ds || a.de > a.T.depth || !a.code || !a.pts || a.n < 0 || a.n > (int64_t(1) << 31))
+    return OFX_EINVAL;
+  if ((((uintptr_t)a.code) & 15) != 0 || (((uintptr_t)a.pts) & 15) != 0) return OFX_EINVAL;
+  return OFX_OK;
+}
+
+extern "C" int ofx_mpu_eval_grad(const ofx_tree_t* tree, int depth_start, int depth_end, const float* pts,
+                                 int64_t n_pts, const float* code, float* sdf, float* grad, uint8_t* mask,
+                                 void* stream) {
+  MpuGradArgs a = {};
+  a.ds = depth_start; a.de = depth_end; a.pts = pts; a.n = n_pts; a.code = code; a.sdf = sdf; a.grad = grad;
+  a.mask = mask;
+  int rc = mpu_grad_check(tree, a);
+  if (rc) return rc;
+  if (!sdf || !grad) return OFX_EINVAL;
+  if (n_pts == 0) return OFX_OK;
+  mpu_grad_kernel<false><<<(unsigned)((n_pts * 8 + 255) / 256), 256, 0, ofx_stream(stream)>>>(a);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+extern "C" int ofx_mpu_backward(const ofx_tree_t* tree, int depth_start, int depth_end, const float* pts,
+                                int64_t n_pts, const float* code, const float* dsdf, const float* dgrad,
+                                float* dcode, void* stream) {
+  MpuGradArgs a = {};
+  a.ds = depth_start; a.de = depth_end; a.pts = pts; a.n = n_pts; a.code = code; a.dsdf = dsdf; a.dgrad = dgrad;
+  a.dcode = dcode;
+  int rc = mpu_grad_check(tree, a);
+  if (rc) return rc;
+  if (!dcode || (!dsdf && !dgrad)) return OFX_EINVAL;
+  if (n_pts == 0) return OFX_OK;
+  mpu_grad_kernel<true><<<(unsigned)((n_pts * 8 + 255) / 256), 256, 0, ofx_stream(stream)>>>(a);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+// ---------------------------------------------------------------------------------
 // Reverse graph for the backward pass of GraphConv (reference: autograd of modules.py:194-220, i.e. of
 // index_select + scatter_mean): forward segment (r, dir) averages x[col] over its cnt edges, so
 //   dx[c] = sum over forward edges e with col_e = c of dcol[row_e, dir_e] / cnt(row_e, dir_e).

@@ -22,12 +22,17 @@ def _corners():
     return torch.tensor([[i >> 2 & 1, i >> 1 & 1, i & 1] for i in range(8)], dtype=torch.float32)
 
 
+def mpu_abs(f):
+    """mpu.py:18-32 (class ABS): |f| whose derivative at 0 is +1 (torch.abs gives 0 there)."""
+    return torch.where(f < 0, -f, f)
+
+
 def linear_pts(octree, depth, pts):
     """mpu.py:55-96 for one depth; returns per (point, corner): node index (-1 absent/out of bounds),
     offsets in cells, weight."""
     scale = 2 ** depth
     xyz = (pts[:, :3] + 1.0) * (scale / 2.0) - 0.5
-    base = torch.floor(xyz)
+    base = torch.floor(xyz).detach()                                   # mpu.py:63
     corners = base.unsqueeze(1) + _corners().to(pts.device)            # [n, 8, 3]
     f = xyz.unsqueeze(1) - corners                                     # [n, 8, 3]
     b = pts[:, 3:4].expand(-1, 8)
@@ -37,7 +42,7 @@ def linear_pts(octree, depth, pts):
     idx = octree.search_key(key, depth).view(-1, 8)
     inb = ((corners > -1) & (corners < scale)).all(-1)
     idx = torch.where(inb, idx, torch.full_like(idx, -1))
-    w = (1.0 - f.abs()).prod(-1) * (depth ** 2 / 50)
+    w = (1.0 - mpu_abs(f)).prod(-1) * (depth ** 2 / 50)
     return idx, f, w
 
 
@@ -61,8 +66,8 @@ def linear_pred(pts, octree, code, depth_start, depth_end):
         c = code[rows.view(-1)].view(n, 8, 4)
         val = (c[..., :3] * (f * (2.0 / 2 ** d))).sum(-1) + c[..., 3]
         wz = torch.where(ok, w, torch.zeros_like(w))
-        num += (wz * val).sum(-1)
-        den += wz.sum(-1)
+        num = num + (wz * val).sum(-1)
+        den = den + wz.sum(-1)
         base += int(octree.nnum[d])
     return num / (den + 1e-8), mask
 

@@ -114,3 +114,16 @@ def encode(sd, cfg, data, doctree):
     """graph_vae.py:162-170: the KL_conv output [N, 2 * embed_dim] (mean | logvar)."""
     h = octree_encoder_step(sd, cfg, data, doctree)[cfg['depth_stop']]
     return h, F.linear(h, sd['KL_conv.linear.weight'], sd['KL_conv.linear.bias'])
+
+
+def forward_train(sd, cfg, data, doctree_in, doctree_out, pos, noise):
+    """GraphVAE.forward with a ground-truth output octree (graph_vae.py:246-289, update_octree False):
+    encoder -> posterior sample with the given noise -> decoder -> NeuralMPU at `pos`.
+    Returns {'logits', 'reg_voxs', 'mpus', 'kl' (elementwise, distributions.py:46), 'z'}."""
+    from . import loss as OL
+    from . import mpu as OM
+    _, params = encode(sd, cfg, data, doctree_in)
+    z, kl = OL.posterior(params, noise)
+    logits, reg_voxs, octree_out = octree_decoder(sd, cfg, z, doctree_out, update_octree=False)
+    mpus = OM.neural_mpu(pos, reg_voxs, octree_out, cfg['full_depth'], cfg['depth_stop'], cfg['depth_out'])
+    return {'logits': logits, 'reg_voxs': reg_voxs, 'mpus': mpus, 'kl': kl, 'z': z, 'octree_out': octree_out}

@@ -426,7 +426,74 @@ def g_mpu():
                    'mask': {d: v[1].clone() for d, v in out.items()}})
 
 
+
+# ---------------------------------------------------------------- G11
+def g_vae_train():
+    """One VAE training forward + losses + parameter gradients from the reference's own code:
+    GraphVAE.forward(octree_in, octree_gt, pos) (graph_vae.py:246-289) -> loss.geometry_loss (loss.py:164-178,
+    'sdf_reg_loss', kl_weight 0.1 as configs/vae_snet_train.yaml:92-95) -> autograd.  The input feature and the
+    posterior noise are given tensors (the reference reads the former from the ocnn octree and draws the latter
+    with torch.randn: both patched to return the recorded inputs)."""
+    import copy
+    from models.networks.dualoctree_networks.graph_vae import GraphVAE
+    from models.networks.dualoctree_networks import loss as RL
+    split, oc, doc = tiny_doctree()
+    sl = C.random_split_large(int(oc.nnum[4]), 11, p=0.3)
+    oc_l = split2octree_large(oc, sl, 4)
+    oc_gt = copy.deepcopy(oc_l)
+    vae = GraphVAE(**VAE_CFG).train()
+    ks = load_filled(vae)
+    doc_l = RD.DualOctree(oc_l)
+    doc_l.post_processing_for_docnn()
+    N6 = doc_l.graph[6]['node_type'].numel()
+    N4 = doc_l.graph[4]['node_type'].numel()
+    data = C.rand_input('vae_enc_in', N6, 4)
+    noise = C.rand_input('vae_post_noise', N4, VAE_CFG['embed_dim'])
+    vae._get_input_feature = lambda d: data
+    n_pts = 2048
+    pos = mpu_points(n_pts, oc_l.batch_size, 33)
+    sdf_gt = C.rand_input('vae_sdf_gt', n_pts, 1).view(-1) * 0.05
+    grad_gt = torch.nn.functional.normalize(C.rand_input('vae_grad_gt', n_pts, 3), dim=1)
+    batch = {'pos': pos.clone().requires_grad_(True), 'sdf': sdf_gt, 'grad': grad_gt}
+    randn, cuda = torch.randn, torch.Tensor.cuda
+
+    def fixed_randn(*shape, **kw):
+        shp = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        assert shp == tuple(noise.shape), shp
+        return noise.clone()
+    torch.randn = fixed_randn
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with torch.enable_grad():
+            out = vae(oc_l, oc_gt, batch['pos'])
+            mpu_grad = {d: g.detach().clone() for d, g in RL.compute_mpu_gradients(out['mpus'], batch['pos']).items()}
+            losses = RL.geometry_loss(batch, out, 'sdf_reg_loss', kl_weight=0.1)
+            total = torch.sum(torch.stack([v for k, v in losses.items() if 'loss' in k]))   # octfusion_model_vae.py:182-183
+            for t in list(out['logits'].values()) + list(out['reg_voxs'].values()):
+                t.retain_grad()
+            total.backward()
+    finally:
+        torch.randn = randn
+        torch.Tensor.cuda = cuda
+    def sub(v, cap=2048):
+        """strided sample of a tensor + its L2 norm (keeps the fixture small; every element still moves the norm)"""
+        f = v.detach().reshape(-1)
+        stride = max(1, -(-f.numel() // cap))
+        return {'stride': stride, 'vals': f[::stride].clone(), 'norm': float(f.double().norm()), 'shape': tuple(v.shape)}
+    grads = {k: sub(p.grad) if p.grad is not None else None for k, p in vae.named_parameters()}
+    rec = {'split_small': split, 'split_large': sl, 'keys': ks, 'cfg': VAE_CFG, 'pos': pos, 'sdf_gt': sdf_gt,
+           'grad_gt': grad_gt, 'kl_weight': 0.1, 'n_noise': tuple(noise.shape),
+           'losses': {k: float(v) for k, v in losses.items()}, 'total': float(total),
+           'logits': {d: sub(v) for d, v in out['logits'].items()},
+           'reg_voxs': {d: sub(v) for d, v in out['reg_voxs'].items()},
+           'd_logits': {d: sub(v.grad) for d, v in out['logits'].items()},
+           'd_reg_voxs': {d: sub(v.grad) for d, v in out['reg_voxs'].items()},
+           'sdf': {d: v[0].detach().clone() for d, v in out['mpus'].items()},
+           'mpu_grad': mpu_grad,
+           'grads': grads}
+    save('g_vae_train', rec)
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['octree_graph', 'modules', 'dense', 'unet', 'sample_loop', 'vae', 'mpu', 'vae_enc']
+    which = sys.argv[1:] or ['octree_graph', 'modules', 'dense', 'unet', 'sample_loop', 'vae', 'mpu', 'vae_enc', 'vae_train']
     for w in which:
         globals()['g_' + w]()

@@ -314,3 +314,63 @@ def test_vae_encoder(golden):
     h, kl = OV.encode(sd, G['cfg'], data, doc_l)
     torch.testing.assert_close(h[::8], G['h_rows8'], rtol=2e-4, atol=2e-5)
     torch.testing.assert_close(kl, G['kl'], rtol=2e-4, atol=2e-5)
+
+
+def sub_close(actual, rec, rtol=2e-3, atol_rel=2e-4):
+    """compare a tensor with a make_golden `sub` record (strided sample + L2 norm)."""
+    f = actual.detach().reshape(-1)
+    assert tuple(actual.shape) == tuple(rec['shape'])
+    scale = float(rec['vals'].abs().max()) + 1e-30
+    torch.testing.assert_close(f[::rec['stride']], rec['vals'], rtol=rtol, atol=atol_rel * scale)
+    assert abs(float(f.double().norm()) - rec['norm']) <= 2e-3 * rec['norm'] + 1e-12
+
+
+def vae_train_case(G):
+    oc, _ = tiny(G['split_small'])
+    oc_l = OS.split2octree_large(oc, G['split_large'], 4)
+    doc_l = OD.OracleDualOctree(oc_l)
+    doc_l.post_processing_for_docnn()
+    sd = C.fill_state_dict(G['keys'])
+    data = C.rand_input('vae_enc_in', doc_l.graph[6]['node_type'].numel(), 4)
+    noise = C.rand_input('vae_post_noise', *G['n_noise'])
+    return oc_l, doc_l, sd, data, noise
+
+
+def test_vae_training_step(golden):
+    """oracle forward_train + geometry_loss + autograd against the reference's own GraphVAE.forward /
+    loss.geometry_loss / backward (tests/golden/g_vae_train.pt): every named loss, the MPU gradients, the
+    gradients w.r.t. logits / reg_voxs and w.r.t. every parameter."""
+    from oracle import loss as OL
+    from oracle import vae as OV
+    G = golden('g_vae_train')
+    oc_l, doc_l, sd, data, noise = vae_train_case(G)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pos = G['pos'].clone().requires_grad_(True)
+    with torch.enable_grad():
+        out = OV.forward_train(sd, G['cfg'], data, doc_l, doc_l, pos, noise)
+        for t in list(out['logits'].values()) + list(out['reg_voxs'].values()):
+            t.retain_grad()
+        mg = OL.mpu_gradients(out['mpus'], pos)
+        losses = OL.geometry_loss(out['logits'], out['mpus'], oc_l, pos, G['sdf_gt'], G['grad_gt'], out['kl'],
+                                  G['kl_weight'])
+        total = OL.total_loss(losses)
+        total.backward()
+    for k, v in G['losses'].items():
+        assert abs(float(losses[k]) - v) <= 2e-4 * abs(v) + 1e-6, (k, float(losses[k]), v)
+    assert abs(float(total) - G['total']) <= 2e-4 * G['total']
+    for d in (4, 5, 6):
+        sub_close(out['logits'][d], G['logits'][d])
+        sub_close(out['reg_voxs'][d], G['reg_voxs'][d])
+        torch.testing.assert_close(out['mpus'][d][0].detach(), G['sdf'][d], rtol=1e-3, atol=1e-4)
+        g_ref = G['mpu_grad'][d]
+        torch.testing.assert_close(mg[d].detach(), g_ref, rtol=2e-3, atol=2e-4 * float(g_ref.abs().max()))
+        sub_close(out['logits'][d].grad, G['d_logits'][d])
+        sub_close(out['reg_voxs'][d].grad, G['d_reg_voxs'][d])
+    n = 0
+    for k, rec in G['grads'].items():
+        if rec is None:
+            assert sd[k].grad is None or float(sd[k].grad.abs().max()) == 0.0, k
+            continue
+        sub_close(sd[k].grad, rec, rtol=5e-3, atol_rel=1e-3)
+        n += 1
+    assert n > 100

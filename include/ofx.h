@@ -112,6 +112,27 @@ typedef struct {
   const int64_t* nnum_nempty_host;
 } ofx_tree_t;
 
+/* Point cloud -> octree -- replaces ocnn `Octree.build_octree` + `merge_octrees` at the reference call sites
+ * models/octfusion_model_union.py:198-212 and models/octfusion_model_vae.py:133-141, and the 'ND' input feature of
+ * the VAE encoder (dual_octree.py:343-360).  The whole batch is built top-down from ONE sorted key array:
+ *   _keys: key[i] = batch << 48 | morton(trunc((p + 1) * 2^(depth-1))) (coordinates clamped to the cube),
+ *          idx[i] = i; batch_id NULL -> every point belongs to element batch_const;
+ *   _sort: stable radix sort of the (key, idx) pairs (ws: ofx_points_sort_ws_bytes(n) bytes);
+ *   _label_from_points: label[j] = 1 iff a point lies in the cell of node j of depth d (node_keys as in
+ *          ofx_octree_grow: batch << 48 | morton_d), for ofx_octree_split;
+ *   _point_features: per node of the finest depth, over its points in input order: feat [nnum,4] =
+ *          (normalize(sum normals), dot(frac(mean scaled position) - 0.5, normal)), zero rows for empty nodes
+ *          (16-B aligned); avg_points / avg_normals [nnum,3] optional (ocnn octree.points / octree.normals). */
+size_t ofx_points_sort_ws_bytes(int64_t n);
+int ofx_points_keys(const float* pts, int64_t ldp, const int32_t* batch_id, int batch_const, int64_t n, int depth,
+                    int64_t* keys, int32_t* idx, void* stream);
+int ofx_points_sort(const int64_t* keys_in, const int32_t* idx_in, int64_t n, int64_t* keys_out, int32_t* idx_out,
+                    void* ws, size_t ws_bytes, void* stream);
+int ofx_octree_label_from_points(const int64_t* sorted_keys, int64_t n_pts, const int64_t* node_keys, int64_t nnum,
+                                 int depth_pts, int d, int32_t* label, void* stream);
+int ofx_octree_point_features(const int64_t* sorted_keys, const int32_t* sorted_idx, int64_t n_pts, const float* pts,
+                              int64_t ldp, const float* normals, int64_t ldn, const int64_t* node_keys, int64_t nnum,
+                              int depth, float* feat, float* avg_points, float* avg_normals, void* stream);
 /* per-depth leaf ranks: leafrank_all[ncum[t] + j] = #leaves before j at depth t.
  * ws: at least ofx_tree_leafrank_ws_bytes(max_d nnum[d]) bytes. */
 size_t ofx_tree_leafrank_ws_bytes(int64_t max_nnum);

@@ -41,6 +41,11 @@ _SIGS = {
     'ofx_split_large_label1': (c_i, [c_p, c_l, c_p, c_p, c_p], True),
     'ofx_octree2voxel_cf': (c_i, [c_p, c_l, c_i, c_i, c_i, c_p, c_p], True),
     'ofx_voxel2octree_cf': (c_i, [c_p, c_i, c_i, c_i, c_p, c_l, c_p], True),
+    'ofx_points_sort_ws_bytes': (c_sz, [c_l], False),
+    'ofx_points_keys': (c_i, [c_p, c_l, c_p, c_i, c_l, c_i, c_p, c_p, c_p], True),
+    'ofx_points_sort': (c_i, [c_p, c_p, c_l, c_p, c_p, c_p, c_sz, c_p], True),
+    'ofx_octree_label_from_points': (c_i, [c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_p], True),
+    'ofx_octree_point_features': (c_i, [c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_p], True),
     'ofx_tree_leafrank_ws_bytes': (c_sz, [c_l], False),
     'ofx_tree_leafrank': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p], True),
     'ofx_graph_nodes': (c_i, [ctypes.POINTER(OfxTree), c_i, c_p, c_p, c_p, c_p, c_p], True),

@@ -229,6 +229,17 @@ class DualOctree:
             self._tf[key] = ops.planes_split(self.type_frac(d, nt), mode)
         return self._tf[key]
 
+    def get_input_feature(self, all_leaf_nodes=True):
+        """dual_octree.py:343-360: the 'ND' feature of the finest octree layer (zero rows for its empty nodes),
+        preceded by zero rows for the leaves of the shallower layers -> [N_depth, 4], the VAE encoder's input."""
+        data = self.octree.get_input_feature('ND', nempty=False)
+        if all_leaf_nodes:
+            n_graph = self.csr(self.depth)[2]
+            out = torch.zeros(n_graph, data.shape[1], dtype=torch.float32, device=data.device)
+            out[n_graph - data.shape[0]:] = data
+            data = out
+        return data
+
     def pad_rows(self, d):
         """int32 [N_d]: position of graph row r inside the node_mask-long padded array
         (graph_vae.py:214-221: `pad[node_mask] = reg`)."""

@@ -90,11 +90,150 @@ class Octree:
         self.nnum[depth] = n
         self.nnum_nempty[depth] = n
 
+    # ---- construction from a point cloud (ocnn Octree.build_octree; call sites
+    #      models/octfusion_model_union.py:198-212, models/octfusion_model_vae.py:133-141) ------------------
+    def build_octree(self, point_cloud):
+        """Build the octree of `point_cloud` (a Points, optionally batched through `batch_id`) down to self.depth:
+        one key sort for the whole batch, then per depth a binary search per node decides which nodes split.
+        Also computes the 'ND' input feature of the finest depth (get_input_feature)."""
+        pts = point_cloud.points
+        if pts.dtype != torch.float32 or not pts.is_cuda:
+            raise _lib.OfxError('build_octree needs fp32 HIP tensors (no CPU path)')
+        pts = pts.contiguous()
+        nrm = point_cloud.normals.contiguous() if point_cloud.normals is not None else None
+        bid = point_cloud.batch_id
+        if bid is not None:
+            bid = bid.reshape(-1).to(torch.int32).contiguous()
+        self.batch_size = int(point_cloud.batch_size)
+        dev = self.device = pts.device
+        n = pts.shape[0]
+        depth = self.depth
+        keys = torch.empty(n, dtype=torch.int64, device=dev)
+        idx = torch.empty(n, dtype=torch.int32, device=dev)
+        call('ofx_points_keys', ptr(pts), pts.stride(0), ptr(bid) if bid is not None else None, 0, n, depth, ptr(keys),
+             ptr(idx), stream())
+        skeys, sidx = torch.empty_like(keys), torch.empty_like(idx)
+        nbytes = _lib.lib().ofx_points_sort_ws_bytes(n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        call('ofx_points_sort', ptr(keys), ptr(idx), n, ptr(skeys), ptr(sidx), ptr(ws), nbytes, stream())
+        for d in range(self.full_depth + 1):
+            self.octree_grow_full(d)
+        for d in range(self.full_depth, depth + 1):
+            nd = int(self.nnum[d])
+            label = torch.empty(nd, dtype=torch.int32, device=dev)
+            call('ofx_octree_label_from_points', ptr(skeys), n, ptr(self.keys[d]), nd, depth, d, ptr(label), stream())
+            self.octree_split(label, d)
+            if d < depth:
+                self.octree_grow(d + 1)
+        nd = int(self.nnum[depth])
+        feat = torch.empty(nd, 4, dtype=torch.float32, device=dev)
+        avg = torch.empty(nd, 3, dtype=torch.float32, device=dev)
+        call('ofx_octree_point_features', ptr(skeys), ptr(sidx), n, ptr(pts), pts.stride(0),
+             ptr(nrm) if nrm is not None else None, nrm.stride(0) if nrm is not None else 0, ptr(self.keys[depth]), nd,
+             depth, ptr(feat), ptr(avg), None, stream())
+        self._feature_nd = feat
+        self._avg_points = avg
+        self._has_normals = nrm is not None
+        return self
+
+    def get_input_feature(self, feature='ND', nempty=False):
+        """ocnn Octree.get_input_feature for the signals the reference asks for (dual_octree.py:345: 'ND'):
+        N = averaged unit normal, D = dot(frac(mean position) - 0.5, normal); rows of empty nodes are zero
+        (octree_pad) unless nempty."""
+        feat = getattr(self, '_feature_nd', None)
+        if feat is None:
+            raise _lib.OfxError('get_input_feature: the octree was not built from a point cloud')
+        cols = []
+        for ch in feature.upper():
+            if ch == 'N':
+                cols.append(feat[:, :3])
+            elif ch == 'D':
+                cols.append(feat[:, 3:4])
+            else:
+                raise ValueError('unsupported feature %r (the reference uses "ND")' % ch)
+        out = cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
+        return out[self.nempty_mask(self.depth)] if nempty else out.contiguous()
+
     def to(self, device):
         return self
 
     def cuda(self):
         return self
+
+
+class Points:
+    """ocnn.octree.Points as the reference uses it (datasets/dualoctree_snet.py:39-47): positions in [-1, 1],
+    optional normals / features, optional per-point batch id."""
+
+    def __init__(self, points, normals=None, features=None, labels=None, batch_id=None, batch_size=1):
+        self.points, self.normals, self.features, self.labels = points, normals, features, labels
+        self.batch_id, self.batch_size = batch_id, batch_size
+        self.device = points.device
+
+    def inbox_mask(self, min=-1.0, max=1.0):
+        return ((self.points >= min) & (self.points <= max)).all(dim=1)
+
+    def clip(self, min=-1.0, max=1.0):
+        """keep the points inside [min, max]^3; returns the mask (index plumbing: one boolean gather per array)."""
+        mask = self.inbox_mask(min, max)
+        for name in ('points', 'normals', 'features', 'labels', 'batch_id'):
+            v = getattr(self, name)
+            if v is not None:
+                setattr(self, name, v[mask])
+        return mask
+
+    def cuda(self, non_blocking=False):
+        for name in ('points', 'normals', 'features', 'labels', 'batch_id'):
+            v = getattr(self, name)
+            if v is not None:
+                setattr(self, name, v.cuda(non_blocking=non_blocking))
+        self.device = self.points.device
+        return self
+
+    to = lambda self, device, **k: self.cuda() if torch.device(device).type == 'cuda' else self   # noqa: E731
+
+
+def merge_points(points_list):
+    """ocnn.octree.merge_points: one batched Points with batch_id = position in the list."""
+    cat = lambda xs: torch.cat(xs, dim=0) if all(x is not None for x in xs) else None      # noqa: E731
+    bid = torch.cat([torch.full((p.points.shape[0],), i, dtype=torch.int32, device=p.points.device)
+                     for i, p in enumerate(points_list)])
+    return Points(cat([p.points for p in points_list]), cat([p.normals for p in points_list]),
+                  cat([p.features for p in points_list]), None, bid, len(points_list))
+
+
+def build_octree_batch(points_list, depth, full_depth):
+    """points2octree per shape + merge_octrees (octfusion_model_union.py:199-209) as ONE build: the batch is keyed,
+    sorted and grown together, so there are no per-shape octrees to merge."""
+    pts = merge_points(points_list)
+    return Octree(depth, full_depth, len(points_list), pts.points.device).build_octree(pts)
+
+
+def merge_octrees(octrees):
+    """ocnn.octree.merge_octrees for octrees built separately (batch size 1 each): per depth, keys get the element's
+    batch id in bits 48.. and child pointers are shifted by the non-empty nodes of the elements before it.
+    (Index plumbing on the per-depth arrays; build_octree_batch avoids it altogether.)"""
+    first = octrees[0]
+    depth, fd = first.depth, first.full_depth
+    out = Octree(depth, fd, len(octrees), first.device)
+    for d in range(depth + 1):
+        keys, children = [], []
+        off = 0
+        for i, oc in enumerate(octrees):
+            assert oc.batch_size == 1 and oc.depth == depth and oc.full_depth == fd
+            keys.append((oc.keys[d] & ((1 << 48) - 1)) | (i << 48))
+            c = oc.children[d]
+            children.append(torch.where(c >= 0, c + off, c))
+            off += int(oc.nnum_nempty[d])
+        out.keys[d] = torch.cat(keys)
+        out.children[d] = torch.cat(children)
+        out.nnum[d] = sum(int(oc.nnum[d]) for oc in octrees)
+        out.nnum_nempty[d] = off
+    feats = [getattr(oc, '_feature_nd', None) for oc in octrees]
+    if all(f is not None for f in feats):
+        out._feature_nd = torch.cat(feats)
+        out._avg_points = torch.cat([oc._avg_points for oc in octrees])
+    return out
 
 
 def create_full_octree(depth, full_depth, batch_size, device='cuda'):

@@ -101,3 +101,29 @@ TINY_HR_CFG = dict(image_size=16, input_depth=5, full_depth=3, in_channels=3, mo
 TINY_LR_CFG = dict(full_depth=3, in_split_channels=8, model_channels=16, out_split_channels=8,
                    attention_resolutions=[2, 4], channel_mult=[1, 2, 4], dims=3,
                    num_classes=None, num_heads=4)
+
+
+def surface_points(n, seed, kind='sphere'):
+    """Synthetic oriented point cloud in [-1, 1]^3: (points [n,3], unit normals [n,3]).  'sphere': radius 0.55 with
+    a seed-dependent offset; 'torus': major 0.5 / minor 0.18.  A few points are snapped to cell boundaries of the
+    depth-6 grid, duplicated, and put on the faces of the cube (the edge cases of the key computation)."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    if kind == 'sphere':
+        v = torch.randn(n, 3, generator=g)
+        nrm = v / v.norm(dim=1, keepdim=True)
+        c = (torch.rand(3, generator=g) - 0.5) * 0.3
+        pts = nrm * 0.55 + c
+    else:
+        u = torch.rand(n, generator=g) * 2 * math.pi
+        w = torch.rand(n, generator=g) * 2 * math.pi
+        R, r = 0.5, 0.18
+        pts = torch.stack([(R + r * torch.cos(w)) * torch.cos(u), (R + r * torch.cos(w)) * torch.sin(u), r * torch.sin(w)], 1)
+        nrm = torch.stack([torch.cos(w) * torch.cos(u), torch.cos(w) * torch.sin(u), torch.sin(w)], 1)
+    k = max(n // 50, 4)
+    pts[:k] = torch.round(pts[:k] * 32) / 32              # exactly on depth-6 cell boundaries
+    pts[k:2 * k] = pts[:k]                                # duplicates
+    pts[2 * k] = torch.tensor([1.0, -1.0, 0.25])          # cube faces / corner
+    pts[2 * k + 1] = torch.tensor([-1.0, -1.0, -1.0])
+    pts[2 * k + 2] = torch.tensor([1.0, 1.0, 1.0])
+    return pts.clamp(-1.0, 1.0).contiguous(), nrm.contiguous()

@@ -374,3 +374,39 @@ def test_vae_training_step(golden):
         sub_close(sd[k].grad, rec, rtol=5e-3, atol_rel=1e-3)
         n += 1
     assert n > 100
+
+
+def test_points_octree_oracle():
+    """oracle/points.py (ocnn's bottom-up build, restated) against a brute-force occupancy pyramid, and through the
+    reference's own octree <-> split codes round trip (utils/util_dualoctree.py:199-273)."""
+    from oracle import points as OP
+    depth, fd = 6, 4
+    clouds = [C.surface_points(3000, 7, 'sphere'), C.surface_points(2500, 8, 'torus')]
+    oc, feat = OP.points2octree_batch([c[0] for c in clouds], [c[1] for c in clouds], depth, fd)
+    assert oc.batch_size == 2 and feat.shape == (int(oc.nnum[depth]), 4)
+    for b, (pts, _) in enumerate(clouds):
+        ijk = ((pts + 1.0) * 2 ** (depth - 1)).long().clamp(0, 2 ** depth - 1)
+        for d in range(fd, depth + 1):
+            occ = torch.zeros(2 ** d, 2 ** d, 2 ** d, dtype=torch.bool)
+            c = ijk >> (depth - d)
+            occ[c[:, 0], c[:, 1], c[:, 2]] = True
+            x, y, z, bb = oc.xyzb(d)
+            sel = bb == b
+            assert torch.equal(oc.nempty_mask(d)[sel], occ[x[sel], y[sel], z[sel]])      # non-empty <=> holds a point
+            assert int(occ.sum()) == int(oc.nempty_mask(d)[sel].sum())                   # and no occupied cell is missing
+    for d in range(depth + 1):
+        assert bool((torch.diff(oc.keys[d]) > 0).all())                                  # sorted, batch-major
+        ne = oc.children[d][oc.children[d] >= 0]
+        assert torch.equal(ne, torch.arange(ne.numel(), dtype=torch.int32))
+        if d < depth:
+            assert int(oc.nnum[d + 1]) == 8 * int(oc.nnum_nempty[d])
+    # the reference's data formats round-trip the structure
+    back = OS.split2octree_small(OS.octree2split_small(oc, fd), depth, fd)
+    for d in range(depth + 1):
+        assert torch.equal(back.keys[d], oc.keys[d])
+        if d < depth:
+            assert torch.equal(back.children[d], oc.children[d])
+    # feature: unit normals on non-empty nodes, |D| <= sqrt(3)/2, zero rows elsewhere
+    ne = oc.nempty_mask(depth)
+    torch.testing.assert_close(feat[ne, :3].norm(dim=1), torch.ones(int(ne.sum())), rtol=1e-5, atol=1e-5)
+    assert float(feat[~ne].abs().max()) == 0.0 and float(feat[:, 3].abs().max()) <= 0.867

@@ -43,7 +43,11 @@ class _Graph(dict):
 
 
 class DualOctree:
-    def __init__(self, octree):
+    def __init__(self, octree, prev=None):
+        """prev: the DualOctree of the SAME octree before it was grown (VAE decoder, graph_vae.py:203-210, where the
+        reference rebuilds everything).  Graph depth d only depends on the keys of depths <= d and the child pointers
+        of depths < d, so every depth whose inputs are still the very same arrays is adopted from `prev` and only
+        the new depths are built."""
         _lib.require_device()
         self.octree = octree
         self.device = octree.device
@@ -88,13 +92,50 @@ class DualOctree:
         self.batch_id_dict = {}
         leaf_base = 0
         self._leaf_base = {}
+        self._src = [(octree.keys[d], octree.children[d], octree.children[d]._version) for d in range(depth + 1)]
+        reuse_to = self._reusable_depth(prev) if prev is not None else fd - 1
+        self.adopted_depths = list(range(fd, reuse_to + 1))
         for d in range(fd, depth + 1):
             self._leaf_base[d] = leaf_base
-            self._build_depth(d, leaf_base + int(self.nnum[d]))
+            if d <= reuse_to:
+                self._adopt(prev, d, unpool_ok=d < reuse_to)
+            else:
+                self._build_depth(d, leaf_base + int(self.nnum[d]))
             leaf_base += int(self.lnum[d])
         self.total_num = self.batch_id_dict[depth].shape[0]
 
     # ------------------------------------------------------------------
+    def _reusable_depth(self, prev):
+        """deepest graph depth of `prev` whose inputs are unchanged (identity of the per-depth arrays)."""
+        if prev.full_depth != self.full_depth or prev.batch_size != self.batch_size or prev.device != self.device:
+            return self.full_depth - 1
+        top = -1
+        for d in range(min(prev.depth, self.depth) + 1):
+            k, c, v = self._src[d]
+            pk, pc, pv = prev._src[d]
+            if k is not pk or int(prev.nnum[d]) != int(self.nnum[d]):
+                break
+            top = d                                     # graph d needs keys[d] but not children[d]
+            if c is not pc or v != pv:
+                break
+        return top if top >= self.full_depth else self.full_depth - 1
+
+    def _adopt(self, prev, d, unpool_ok):
+        for name in ('_csr', '_nbr', '_ext', '_bid32', '_ntype8', 'batch_id_dict', '_count'):
+            getattr(self, name)[d] = getattr(prev, name)[d]
+        if d in prev._rev:
+            self._rev[d] = prev._rev[d]
+        g = _Graph(self, d)
+        for k, v in dict.items(prev.graph[d]):
+            dict.__setitem__(g, k, v)
+        self.graph[d] = g
+        for key, v in prev._tf.items():
+            if (key[1] if key[0] == 'tfp' else key[0]) == d:
+                self._tf[key] = v
+        for key, v in prev._maps.items():
+            if key[1] == d and (key[0] in ('pad', 'pool') or (key[0] == 'unpool' and unpool_ok)):
+                self._maps[key] = v
+
     def _build_depth(self, d, N):
         dev = self.device
         tree = ctypes.byref(self._tree)
@@ -103,7 +144,13 @@ class DualOctree:
         seg_ptr = torch.empty(N * 7 + 1, dtype=torch.int32, device=dev)
         ws = torch.empty(_lib.lib().ofx_scan_ws_bytes(N * 7), dtype=torch.uint8, device=dev)
         call('ofx_scan_i32', ptr(seg_cnt), ptr(seg_ptr), N * 7, ptr(ws), stream())
-        E = int(seg_ptr[-1].item())                      # host sync: sizes the column array
+        # the multi-neighbour ranks only need the segment sizes, so both totals (edges, multi-neighbour segments)
+        # come back in ONE host read per depth -- they size the column array and the pre-averaged-row scratch
+        flag = seg_cnt
+        call('ofx_graph_multi_flag', ptr(seg_ptr), N, ptr(flag), stream())
+        rank = torch.empty(N * 7 + 1, dtype=torch.int32, device=dev)
+        call('ofx_scan_i32', ptr(flag), ptr(rank), N * 7, ptr(ws), stream())
+        E, V = torch.stack([seg_ptr[-1], rank[-1]]).tolist()
         col = torch.empty(E, dtype=torch.int32, device=dev)
         call('ofx_graph_fill', tree, d, ptr(seg_ptr), ptr(col), stream())
         bid = torch.empty(N, dtype=torch.int32, device=dev)
@@ -116,11 +163,6 @@ class DualOctree:
         nbr = torch.empty(N * 7, dtype=torch.int32, device=dev)
         call('ofx_graph_primary', ptr(seg_ptr), ptr(col), N, ptr(nbr), stream())
         self._nbr[d] = nbr
-        flag = torch.empty(N * 7, dtype=torch.int32, device=dev)
-        call('ofx_graph_multi_flag', ptr(seg_ptr), N, ptr(flag), stream())
-        rank = torch.empty(N * 7 + 1, dtype=torch.int32, device=dev)
-        call('ofx_scan_i32', ptr(flag), ptr(rank), N * 7, ptr(ws), stream())
-        V = int(rank[-1].item())
         nbr_ext = torch.empty(N * 7, dtype=torch.int32, device=dev)
         multi_seg = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
         call('ofx_graph_primary_ext', ptr(seg_ptr), ptr(col), N, ptr(rank), ptr(nbr_ext), ptr(multi_seg), stream())

@@ -163,7 +163,7 @@ class GraphVAE(nn.Module):
                 if d < self.depth_out:
                     octree_out.octree_grow(d + 1)
                     octree_out.depth += 1
-                doctree_out = DualOctree(octree_out)
+                doctree_out = DualOctree(octree_out, prev=doctree_out)       # only the new depth is built
             reg = self.regress[i][1](self.regress[i][0]((deconv, doctree_out, d)))
             # pad to [leaves-so-far(all nodes) + nodes at d] rows (graph_vae.py:214-221) with a row map
             node_mask = doctree_out.graph[d]['node_mask']

@@ -1109,3 +1109,47 @@ def test_full_size_shell6_b8_properties():
         assert float((rows.var(dim=(0, 2), unbiased=False) - 1).abs().max()) < 1e-3
     gw = OM.dual_octree_group_norm(y.cpu(), o_doc, 6, torch.ones(1, 128), torch.zeros(1, 128))
     close(g, gw, 1e-4)
+
+
+@pytest.mark.gpu
+def test_incremental_dual_octree(golden):
+    """DualOctree(octree, prev=...) (the VAE growth path, graph_vae.py:203-210) adopts every depth whose inputs are
+    unchanged and builds only the new one; the result equals a full rebuild, array for array."""
+    from octfusion_amd.dual_octree import DualOctree
+    from octfusion_amd.octree import split2octree_small
+    oc = split2octree_small(C.shell6_split(2, jitter=True).to(dev()), 6, 4)      # depth 6, children[6] all -1
+    doc6 = DualOctree(oc)
+    doc6.type_frac(6, 5), doc6.pool_maps(6), doc6.unpool_maps(5), doc6.pad_rows(6), doc6.rev(5)      # populate caches
+    g = torch.Generator().manual_seed(4)
+    label = (torch.rand(int(oc.nnum[6]), generator=g) < 0.4).to(torch.int32).to(dev())
+    oc.octree_split(label, 6)
+    oc.octree_grow(7)
+    oc.depth += 1
+    inc = DualOctree(oc, prev=doc6)
+    full = DualOctree(oc)
+    assert inc.adopted_depths == [4, 5, 6] and full.adopted_depths == []
+    assert inc.total_num == full.total_num
+    for d in range(4, 8):
+        a, b = inc.csr(d), full.csr(d)
+        assert a[2:] == b[2:] and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert torch.equal(inc.ext(d)[0], full.ext(d)[0]) and inc.ext(d)[2] == full.ext(d)[2]
+        assert torch.equal(inc.batch_id(d), full.batch_id(d)) and torch.equal(inc.count(d), full.count(d))
+        for k in ('node_type', 'keyd', 'node_mask', 'edge_idx', 'edge_dir'):
+            assert torch.equal(inc.graph[d][k], full.graph[d][k]), (d, k)
+        assert torch.equal(inc.type_frac(d, d - 1), full.type_frac(d, d - 1))
+        assert torch.equal(inc.pad_rows(d), full.pad_rows(d))
+        if d > 4:
+            for x, y in zip(inc.pool_maps(d), full.pool_maps(d)):
+                assert x == y if isinstance(x, int) else torch.equal(x, y)
+        if d < 7:
+            for x, y in zip(inc.unpool_maps(d), full.unpool_maps(d)):       # depth 6 changed: must NOT be adopted
+                assert x == y if isinstance(x, int) else torch.equal(x, y)
+    assert inc.csr(6)[0] is doc6.csr(6)[0]                                   # adopted, not copied or rebuilt
+    # a split at the last depth without growth: nothing to build at all
+    label7 = (torch.rand(int(oc.nnum[7]), generator=g) < 0.5).to(torch.int32).to(dev())
+    oc.octree_split(label7, 7)
+    last = DualOctree(oc, prev=inc)
+    assert last.adopted_depths == [4, 5, 6, 7] and torch.equal(last.node_child(7), oc.children[7])
+    # an unrelated octree adopts nothing
+    other = split2octree_small(C.shell6_split(2, jitter=True).to(dev()), 6, 4)
+    assert DualOctree(other, prev=doc6).adopted_depths == []

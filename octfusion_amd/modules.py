@@ -362,6 +362,17 @@ class GraphResBlockEmbed(TimestepBlock):
         """``emb_act``: optional precomputed SiLU(emb) shared by all blocks of a step; ``emb_out``: optional
         precomputed emb_layers(emb) [B, Cout] (the U-Net evaluates the emb_layers of ALL its blocks in one GEMM);
         ``out``: optional destination (may be a column slice of a wider buffer: zero-copy skip concatenation)."""
+        skip, side = x, None
+        if not isinstance(self.skip_connection, nn.Identity):
+            if ops.SIDE_STREAM:
+                # the 1x1 skip convolution only depends on x: run it on the side stream, where it fills the CUs the
+                # conv1 chain leaves idle (tile-count tails, prologues); joined right before conv2 adds it
+                main, side = torch.cuda.current_stream(x.device), ops.side_stream(x.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    skip = self.skip_connection(x)
+            else:
+                skip = self.skip_connection(x)
         h = self.block1_norm(x, doctree, depth, act='silu', planes=self.conv1.planes_mode(doctree, depth))
         if emb_out is None:
             if emb_act is None:
@@ -370,7 +381,8 @@ class GraphResBlockEmbed(TimestepBlock):
         assert doctree.batch_size == emb_out.shape[0]
         h = self.conv1(h, doctree, depth, emb=emb_out)              # + emb_out[batch_id] fused
         h = self.block2_norm(h, doctree, depth, act='silu', out=h, planes=self.conv2.planes_mode(doctree, depth))
-        skip = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x)
+        if side is not None:
+            main.wait_stream(side)
         return self.conv2(h, doctree, depth, res=skip, out=out)     # skip + h fused
 
 

@@ -5,6 +5,8 @@ current torch HIP stream.  Inputs must be CUDA (HIP) tensors; nothing here has
 a CPU implementation -- a CPU tensor raises.
 """
 import contextlib
+import os
+
 import torch
 
 from . import _lib
@@ -204,9 +206,24 @@ def graphconv_planes(xp, mode, seg_ptr, col, ext, pw, cin, nt, tf_planes=None, b
     return out
 
 
+# OFX_SIDE_STREAM=1: run the 1x1 skip convolutions of the res-blocks on a second stream, concurrently with the conv1
+# chain.  Off by default: measured SLOWER on MI355X (hr step 9.44 ms vs 9.19 ms, graph replay) -- the dense GEMM's
+# blocks take CU slots from the co-resident GraphConv blocks instead of only filling its tile-count tail.
+SIDE_STREAM = os.environ.get('OFX_SIDE_STREAM', '0') == '1'
+_SIDE = {}
+
+
+def side_stream(device):
+    """The per-device side stream for work that is independent of the main chain (joined before its result is used)."""
+    s = _SIDE.get(device.index)
+    if s is None:
+        s = _SIDE[device.index] = torch.cuda.Stream(device)
+    return s
+
+
 def workspace(device, nbytes=64 << 20):
-    """Per-device split-K scratch (partial tiles); reused by every launch on the stream."""
-    key = (device.type, device.index)
+    """Per-(device, stream) split-K scratch (partial tiles); reused by every launch on that stream."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(nbytes, dtype=torch.uint8, device=device)

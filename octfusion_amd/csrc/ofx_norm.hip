@@ -15,15 +15,26 @@
 // and ~0.85 TB/s).  Each block reduces its rows in LDS and issues one fp64 atomic pair per channel.
 constexpr int GN_ROWS_PER_BLOCK = 64;
 
+// rows per block of the two statistics kernels.  Each block ends with ONE fp64 atomic pair per channel, so an address
+// (batch element, channel) receives blocks / batch_size atomics, and a same-address device atomic costs ~100-270 ns
+// (measured: 780 k rows x 32 channels, batch 4, 64-row blocks -> 3 k atomics per address, 318 us = 0.3 TB/s; 64 k rows
+// -> 253 per address, 69 us for 8 MB).  Blocks are therefore capped at 128 per batch element (at least 256: enough
+// to stream) and own proportionally more consecutive rows.
+static inline int64_t gn_stats_rows(int64_t n, int batch_size) {
+  const int64_t chunks = (n + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK;
+  int64_t cap = 128 * (int64_t)batch_size;
+  if (cap < 256) cap = 256;
+  return chunks <= cap ? GN_ROWS_PER_BLOCK : GN_ROWS_PER_BLOCK * ((chunks + cap - 1) / cap);
+}
+
 __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int C,
-                                                       const int32_t* __restrict__ bid, double* __restrict__ sums) {
+                                                       const int32_t* __restrict__ bid, double* __restrict__ sums,
+                                                       int64_t rpb) {
   __shared__ int sb[256];
   __shared__ float sv[256][8];
   const int CT = C >> 2;                 // float4 lanes per row (<= 256)
   const int RP = 256 / CT;               // rows per pass
   const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
-  const int64_t r_begin = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK;
-  const int64_t r_end = r_begin + GN_ROWS_PER_BLOCK < n ? r_begin + GN_ROWS_PER_BLOCK : n;
   int cb = -1;
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   auto flush_direct = [&](int b, const float* ps, const float* pq) {
@@ -45,6 +56,10 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
     s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
     q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
   };
+  // a block owns `rpb` CONSECUTIVE rows (64, or more for long narrow tensors: see gn_stats_rows): consecutive rows
+  // share a batch element except at the few run boundaries, where a thread flushes its run with its own atomics
+  const int64_t r_begin = (int64_t)blockIdx.x * rpb;
+  const int64_t r_end = r_begin + rpb < n ? r_begin + rpb : n;
   if (rl < RP) {
     int64_t r = r_begin + rl;
     // 4 independent 16-B loads in flight per lane
@@ -90,7 +105,8 @@ extern "C" int ofx_gn_stats(const float* x, int64_t ldx, int64_t n, int C, const
     return OFX_EINVAL;
   hipStream_t st = ofx_stream(stream);
   if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)batch_size * C, st) != hipSuccess) return OFX_ELAUNCH;
-  if (n > 0) gn_stats_kernel<<<(int)ofx_cdiv(n, GN_ROWS_PER_BLOCK), 256, 0, st>>>(x, ldx, n, C, batch_id, sums);
+  if (n > 0) gn_stats_kernel<<<(int)ofx_cdiv(n, gn_stats_rows(n, batch_size)), 256, 0, st>>>(x, ldx, n, C, batch_id, sums,
+                                                                                          gn_stats_rows(n, batch_size));
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
@@ -336,13 +352,11 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restri
                                                            const int32_t* __restrict__ bid,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
-                                                           int act, double* __restrict__ sums) {
+                                                           int act, double* __restrict__ sums, int64_t rpb) {
   __shared__ int sb[256];
   __shared__ float sv[256][8];
   const int CT = C >> 2, RP = 256 / CT;
   const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
-  const int64_t r_begin = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK;
-  const int64_t r_end = r_begin + GN_ROWS_PER_BLOCK < n ? r_begin + GN_ROWS_PER_BLOCK : n;
   int cb = -1;
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   auto flush_direct = [&](int b, const float* ps, const float* pq) {
@@ -354,6 +368,8 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restri
   if (rl < RP) {
     const float4 ww = *reinterpret_cast<const float4*>(w + cl * 4);
     const float4 bb = *reinterpret_cast<const float4*>(bias + cl * 4);
+    const int64_t r_begin = (int64_t)blockIdx.x * rpb;
+    const int64_t r_end = r_begin + rpb < n ? r_begin + rpb : n;
     for (int64_t r = r_begin + rl; r < r_end; r += RP) {
       const int b = bid[r];
       if (b != cb) {
@@ -490,7 +506,8 @@ extern "C" int ofx_gn_backward(const float* x, int64_t ldx, const float* dy, int
   hipStream_t st = ofx_stream(stream);
   if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)batch_size * C, st) != hipSuccess) return OFX_ELAUNCH;
   if (n > 0)
-    gn_bwd_stats_kernel<<<(int)ofx_cdiv(n, GN_ROWS_PER_BLOCK), 256, 0, st>>>(x, ldx, dy, ldy, n, C, batch_id, mean, rstd, w, bias, act, sums);
+    gn_bwd_stats_kernel<<<(int)ofx_cdiv(n, gn_stats_rows(n, batch_size)), 256, 0, st>>>(x, ldx, dy, ldy, n, C, batch_id, mean, rstd, w, bias,
+                                                                                 act, sums, gn_stats_rows(n, batch_size));
   const int work = batch_size * groups > C ? batch_size * groups : C;
   gn_bwd_finalize_kernel<<<(work + 63) / 64, 64, 0, st>>>(sums, count, batch_size, C, groups, count_eps, mean, rstd, w,
                                                           coef, dgamma, dbeta);

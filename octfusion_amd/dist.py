@@ -62,6 +62,45 @@ def broadcast_module_(module, src=0):
     return total * 4
 
 
+@torch.no_grad()
+def all_reduce_mean_(grads, bucket_bytes=256 << 20):
+    """Data-parallel training (the reference wraps its nets in DistributedDataParallel: octfusion_model_union.py:185-196,
+    octfusion_model_vae.py:121-130): average the gradient dict over the ranks in place.  Gradients are packed, in
+    sorted key order, into flat fp32 buckets of up to `bucket_bytes` -- a few large ring all-reduces (per-link bound on
+    xGMI, so size matters more than count) instead of one per tensor.  Every rank must hold the same keys; a key that
+    is missing on some rank (a parameter without gradient there) is an error the caller has to resolve.
+    Returns the number of bytes reduced."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    keys = sorted(grads)
+    total = 0
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size, total
+        if not bucket:
+            return
+        flat = torch.cat([grads[k].reshape(-1).float() for k in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= world
+        off = 0
+        for k in bucket:
+            n = grads[k].numel()
+            grads[k].copy_(flat[off:off + n].view_as(grads[k]))
+            off += n
+        total += flat.numel() * 4
+        bucket, size = [], 0
+    for k in keys:
+        nb = grads[k].numel() * 4
+        if bucket and size + nb > bucket_bytes:
+            flush()
+        bucket.append(k)
+        size += nb
+    flush()
+    return total
+
+
 def max_over_ranks(value, device):
     """MAX all-reduce of a python float (timing)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

@@ -22,6 +22,10 @@ class AdamW:
 
     @torch.no_grad()
     def step(self, grads):
+        """One AdamW update.  Under torch.distributed (one process per GPU) the gradients are first averaged over the
+        ranks (dist.all_reduce_mean_: what DistributedDataParallel does for the reference)."""
+        from . import dist as D
+        D.all_reduce_mean_(grads)
         self.step_count += 1
         for k, p in self.params.items():
             g = grads.get(k)

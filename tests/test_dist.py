@@ -95,3 +95,33 @@ def test_generate_shards_like_the_reference():
             ref.append(it * world + rank)
             it += 1
         assert shard_indices(total, rank, world) == ref
+
+
+def _grad_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from octfusion_amd import dist as D
+    D.init(backend='gloo')
+    g = torch.Generator().manual_seed(7 + rank)
+    grads = {'b.weight': torch.randn(33, 5, generator=g), 'a.bias': torch.randn(5, generator=g),
+             'c.weights': torch.randn(1000, generator=g)}
+    mine = {k: v.clone() for k, v in grads.items()}
+    nbytes = D.all_reduce_mean_(grads, bucket_bytes=1024)            # small buckets: several collectives
+    gathered = {}
+    for k, v in mine.items():
+        parts = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(parts, v)
+        gathered[k] = sum(parts) / world
+    ok = all(torch.allclose(grads[k], gathered[k], rtol=0, atol=1e-6) for k in grads)
+    if rank == 0:
+        torch.save({'ok': ok, 'nbytes': nbytes, 'numel': sum(v.numel() for v in grads.values())}, out)
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_world2(tmp_path):
+    """data-parallel training: the bucketed gradient average equals the mean of the per-rank gradients."""
+    out = str(tmp_path / 'g.pt')
+    mp.spawn(_grad_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r['ok'] and r['nbytes'] == 4 * r['numel']

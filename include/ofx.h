@@ -384,6 +384,7 @@ int ofx_set_gconv2_tile(int wm);
 /* start offset between the two co-resident blocks of a CU (128-row geometry), in shader clocks per k tile of the
  * layer; 0 = start together -- A/B knob */
 int ofx_set_gconv2_stagger(int clocks_per_ktile);
+int ofx_set_gconv2_prefetch(int on);   /* 1 (default): block b pulls the table slice of block b + resident blocks into L2 */
 /* profiling aid: when buf != NULL every block of the following ofx_graphconv_fwd_planes launches writes 8 uint64
  * to buf[block*8..]: shader-clock stamps at start / table built / first tile landed / k-loop done / stores drained,
  * then HW_ID.  buf must hold 8 * (tiles of the largest launch) uint64.  NULL switches it off. */

@@ -107,6 +107,7 @@ _SIGS = {
     'ofx_set_gconv2_debug': (c_i, [c_p], True),
     'ofx_set_gconv2_tile': (c_i, [c_i], True),
     'ofx_set_gconv2_stagger': (c_i, [c_i], True),
+    'ofx_set_gconv2_prefetch': (c_i, [c_i], True),
     'ofx_graph_multi_flag': (c_i, [c_p, c_l, c_p, c_p], True),
     'ofx_graph_primary_ext': (c_i, [c_p, c_p, c_l, c_p, c_p, c_p, c_p], True),
     'ofx_graph_primary': (c_i, [c_p, c_p, c_l, c_p, c_p], True),

@@ -57,7 +57,8 @@ template <int WM, int NI = 2> struct G2Cfg {
   static constexpr int A_BYTES = BM * G2_LINE;
   static constexpr int BUF = A_BYTES + B_BYTES;       // one stage
   static constexpr int TAB = NBUF * BUF;              // neighbour-table slice [BM][8] uint32
-  static constexpr int LDS = TAB + BM * 8 * 4;        // 155 648 B (WM 4) / 69 632 B (WM 2)
+  static constexpr int PFS = TAB + BM * 8 * 4;        // 256-B landing pad of the table prefetch (never read)
+  static constexpr int LDS = PFS + 256;               // 155 904 B (WM 4) / 69 888 B (WM 2)
   static constexpr int B_PER_WAVE = (BN / 8) / WAVES;                 // weight-tile DMA instructions per wave: 1, 2 or 4
   static constexpr int READS = 2 * (G2_MI + NI);                      // LDS reads of one half-step fragment set
   static constexpr int EPI_LOADS = G2_MI * NI * 4 + NI + G2_MI * 4;   // epilogue operand requests per lane (26 / 17)
@@ -74,6 +75,8 @@ struct Gemm2Args {
   int tpd, nkt_g, nkt;                    // k tiles per direction, gather tiles (7 * tpd), all tiles
   unsigned long long* dbg;                // optional [blocks][8] shader-clock stamps (ofx_set_gconv2_debug)
   int stagger;                            // shader clocks the second block of each CU waits before its first tile (WM 2)
+  int prefetch;                           // > 0: number of co-resident blocks; block b pulls the neighbour-table slice of
+                                          // block b + prefetch (same XCD, one round later) into L2
   int64_t row0;                           // first output row of this launch (bulk + remainder launches split the rows)
   GemmArgs e;                             // M, N, epilogue operands, tile grid
 };
@@ -414,6 +417,24 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
   }
   __syncthreads();
   if (dbg) ts1 = g2_clock();
+
+  // ---- table prefetch for the next round.  The table build above is one exposed HBM miss per block (the 6 MB
+  // nbr_ext array is long gone from the caches when the next convolution reads it); block b + S runs on the same XCD
+  // one round later (S = co-resident blocks, a multiple of 8), so wave 0 pulls that block's slice (BM * 28 B) into this
+  // XCD's L2 now with a DMA load whose LDS destination is never read -- no register, no wait: it is older than every
+  // counted load of the pipeline.
+  if (a.prefetch > 0 && wid == 0) {
+    int nb = (int)blockIdx.x + a.prefetch;
+    if (nb < ntile) {
+      const int q = ntile / 8, r = ntile % 8, xcd = nb % 8, j = nb / 8;
+      nb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+      const int64_t m2 = a.row0 + (int64_t)(nb / g.ntn) * G2_BM;
+      gcp p = (gcp)(a.nbr_ext + m2 * 7) + lane * 128;
+      gcp last = (gcp)(a.nbr_ext + g.M * 7) - 4;
+      if (lane * 128 < G2_BM * 28 + 128 && p <= last)
+        __builtin_amdgcn_global_load_lds(p, (ldsp)(smem2 + CF::PFS), 4, 0, 0);
+    }
+  }
 
   // ---- wave-uniform loop operands pinned in SGPRs
   auto sgpr32 = [](int v) {
@@ -1074,6 +1095,11 @@ extern "C" int ofx_set_gconv2_stagger(int clocks_per_ktile) {
   g2_stagger_per_ktile = clocks_per_ktile;
   return OFX_OK;
 }
+static int g2_prefetch = 1;                 // table prefetch one round ahead (A/B knob)
+extern "C" int ofx_set_gconv2_prefetch(int on) {
+  g2_prefetch = on ? 1 : 0;
+  return OFX_OK;
+}
 extern "C" int ofx_set_gconv2_tile(int wm) {
   if (wm != 0 && wm != 2 && wm != 4) return OFX_EINVAL;
   g2_wm = wm;
@@ -1139,6 +1165,7 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
     a.row0 = row0;
     g.ntm = (int)ofx_cdiv(rows, wm * 64);
     a.stagger = wm == 2 ? g2_stagger_per_ktile * a.nkt : 0;
+    a.prefetch = g2_prefetch ? (wm == 2 ? 512 : 256) : 0;
     if (mode == 2) {
       switch (g2_variant) {
         case 0: return G2_GO(2, 0, wm);

@@ -25,4 +25,11 @@ at THAT boundary (octree container + Morton key codec + octree2voxel/pad) the
 semantics are restated from ocnn-pytorch's public API and the invariants the
 reference relies on -- parity at the ocnn boundary is
 UNPINNED; everything above it is pinned by the golden vectors.
+
+Training side: ``oracle/loss.py`` + ``vae.forward_train`` (the VAE objective and its autograd
+gradients) are PINNED by ``tests/golden/g_vae_train.pt`` -- the reference's own GraphVAE.forward +
+loss.geometry_loss + backward, every named loss and every parameter gradient.  ``oracle/points.py`` (point cloud ->
+octree) restates ocnn's published build_octree / merge_octrees: that is the ocnn boundary again, so it is UNPINNED;
+it is cross-checked against a brute-force occupancy pyramid and through the reference's octree <-> split-code round
+trip (which IS pinned).
 """

@@ -75,8 +75,9 @@ struct Gemm2Args {
   int tpd, nkt_g, nkt;                    // k tiles per direction, gather tiles (7 * tpd), all tiles
   unsigned long long* dbg;                // optional [blocks][8] shader-clock stamps (ofx_set_gconv2_debug)
   int stagger;                            // shader clocks the second block of each CU waits before its first tile (WM 2)
-  int prefetch;                           // > 0: number of co-resident blocks; block b pulls the neighbour-table slice of
-                                          // block b + prefetch (same XCD, one round later) into L2
+  int prefetch;                           // number of co-resident blocks S (256 x blocks per CU); block b pulls the
+                                          // neighbour-table slice of block b + S (same XCD, one round later) into L2
+  int prefetch_on;
   int64_t row0;                           // first output row of this launch (bulk + remainder launches split the rows)
   GemmArgs e;                             // M, N, epilogue operands, tile grid
 };
@@ -378,14 +379,17 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
   const int l31 = lane & 31, h = lane >> 5;
   const bool dbg = a.dbg != nullptr;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
-  if (WM == 2 && a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-    // Two blocks share a CU and all 512 first-round blocks start together, so their prologues, k-loops and
-    // epilogues coincide and nothing overlaps.  The second block of every CU (dispatch order observed on gfx950:
-    // block b -> XCD b % 8, CU (b / 8) % 32, i.e. blocks 256..511 are the second slots; only speed depends on this)
-    // idles for about half a tile once: the pair then stays out of phase for the whole launch and one block's
-    // table build / DMA latency / residual reads / stores run under the other block's MFMAs.
+  if (WM == 2 && a.stagger > 0 && blockIdx.x >= 256 && (int)blockIdx.x < a.prefetch) {
+    // Two (three with 64-column tiles: 52 KB of LDS each) blocks share a CU and all first-round blocks start together,
+    // so their prologues, k-loops and epilogues coincide and nothing overlaps.  Dispatch order observed on gfx950:
+    // block b -> XCD b % 8, CU (b / 8) % 32, i.e. blocks 256..511 (and 512..767) are the later slots of every CU; only
+    // speed depends on this.  Slot g of n idles for g/n of a tile once (a.stagger = half a tile): the co-resident
+    // blocks then stay out of phase for the whole launch and one block's table build / DMA latency / residual reads /
+    // stores run under the others' MFMAs.
+    const int grp = (int)blockIdx.x >> 8, ngrp = a.prefetch >> 8;
+    const unsigned long long wait = (unsigned long long)a.stagger * 2ull * grp / ngrp;
     const unsigned long long t0 = g2_clock();
-    while (g2_clock() - t0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(32);
+    while (g2_clock() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
   if (dbg) ts0 = g2_clock();
 
@@ -423,7 +427,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
   // one round later (S = co-resident blocks, a multiple of 8), so wave 0 pulls that block's slice (BM * 28 B) into this
   // XCD's L2 now with a DMA load whose LDS destination is never read -- no register, no wait: it is older than every
   // counted load of the pipeline.
-  if (a.prefetch > 0 && wid == 0) {
+  if (a.prefetch_on && wid == 0) {
     int nb = (int)blockIdx.x + a.prefetch;
     if (nb < ntile) {
       const int q = ntile / 8, r = ntile % 8, xcd = nb % 8, j = nb / 8;
@@ -1096,12 +1100,14 @@ extern "C" int ofx_set_gconv2_stagger(int clocks_per_ktile) {
   return OFX_OK;
 }
 static int g2_prefetch = 1;                 // table prefetch one round ahead (A/B knob)
+static int g2_slots3 = 1;                   // 64-column tiles: assume three co-resident blocks per CU (A/B: bit 1 of `on`)
 extern "C" int ofx_set_gconv2_prefetch(int on) {
-  g2_prefetch = on ? 1 : 0;
+  g2_prefetch = (on & 1) ? 1 : 0;
+  g2_slots3 = (on & 2) ? 0 : 1;             // on = 1: default; on = 3: prefetch with the two-slot assumption
   return OFX_OK;
 }
 extern "C" int ofx_set_gconv2_tile(int wm) {
-  if (wm != 0 && wm != 2 && wm != 4) return OFX_EINVAL;
+  if (wm != 0 && wm != 1 && wm != 2 && wm != 4) return OFX_EINVAL;     // 1: automatic without the long-tensor rule (A/B)
   g2_wm = wm;
   return OFX_OK;
 }
@@ -1151,8 +1157,8 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
       g.stats_part = (float*)ws; g.stats_part_bytes = ws_bytes;
     }
   }
-  // ---- geometry: one output-column tile (cout <= 128) -> 128-row tiles, two staggered blocks per CU (prologue /
-  // epilogue overlap, +3-9 %); several column tiles -> 256-row tiles (larger weight-tile reuse, cout 256 / 512 layers
+  // ---- geometry: one output-column tile (cout <= 128) -> 128-row tiles, two (64-column tiles: three) staggered blocks
+  // per CU (prologue / epilogue overlap, +3-9 %); several column tiles -> 256-row tiles (larger weight-tile reuse, cout 256 / 512 layers
   // +5-15 %).  Splitting the rows into a bulk launch of whole "rounds" of 256-row tiles plus a remainder launch of
   // 128-row tiles (against tile quantisation: 530 tiles on 256 CUs = 2.07 rounds) was built and measured: no gain
   // (blocks do not run in lock-step rounds, and the second launch pays its own fill and drain) --
@@ -1165,7 +1171,8 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
     a.row0 = row0;
     g.ntm = (int)ofx_cdiv(rows, wm * 64);
     a.stagger = wm == 2 ? g2_stagger_per_ktile * a.nkt : 0;
-    a.prefetch = g2_prefetch ? (wm == 2 ? 512 : 256) : 0;
+    a.prefetch = wm == 4 ? 256 : (ni == 1 && g2_slots3 ? 768 : 512);      // co-resident blocks (LDS-bound: 1 / 2 / 3 per CU)
+    a.prefetch_on = g2_prefetch;
     if (mode == 2) {
       switch (g2_variant) {
         case 0: return G2_GO(2, 0, wm);
@@ -1180,7 +1187,10 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
     }
     return g2_variant == 0 ? G2_GO(1, 0, wm) : (g2_variant == 1 ? G2_GO(1, 1, wm) : G2_GO(1, 5, wm));
   };
-  rc = launch(g2_wm ? g2_wm : (cout <= 128 ? 2 : 4), 0, g.M);
+  // narrow layers on very long tensors (depth 7 / 8 of the feature net: >= 8 rounds of 256-row tiles) amortise the
+  // prologue better with the 256-row geometry too: 2-5 % (tools/gconv2_tile_d8.py)
+  const int64_t tiles4 = ofx_cdiv(g.M, 256) * g.ntn;
+  rc = launch(g2_wm > 1 ? g2_wm : ((cout <= 128 && (tiles4 < 2048 || g2_wm == 1)) ? 2 : 4), 0, g.M);
 #undef G2_GO
   if (rc) return rc;
   if (g.stats_part) {

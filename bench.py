@@ -366,34 +366,45 @@ def main():
     # ---- execution mode of the timed region: the whole step (U-Net forward + DDIM update) captured once into a
     # hipGraph and replayed -- what sampler.sample_loop does by default: every shape is static across the steps of a
     # stage (the doctree is fixed), only x / log-SNR / coefficients / noise change and they live in static buffers.
-    # Falls back to eager launches if capture fails (and for the lr stage, whose self-conditioning input alternates).
+    # The lr stage has two regimes (with / without the sign() of the truncated steps) -> one graph each, and its
+    # self-conditioning input (the previous step's x0 prediction) is copied into a static buffer after every replay.
+    # Falls back to eager launches if capture fails.
     replay = None
-    if not args.eager and args.workload != 'lr':
+    if not args.eager:
         try:
+            is_lr = wl.stage == 'lr'
             cond_s = wl.cond[0].expand(batch).contiguous().clone()
             coef_s = wl.coef[0].clone()
-            noise_s = torch.randn_like(wl.x) if wl.df == 'x0' else None
+            noise_s = torch.randn_like(wl.x) if wl.df == 'x0' else None      # multiplied by coef[3] (0 on noise-free steps)
+            self_s = torch.zeros_like(wl.x) if is_lr else None               # no self-conditioning on the first step = zeros
 
-            def gstep():
-                wl.sampler._step(wl.net, wl.x, cond_s, wl.stage, wl.df, wl.doc, wl.nested, wl.label, None, coef_s,
-                                 noise_s, False, None)
-            gph = torch.cuda.CUDAGraph()
-            side_s = torch.cuda.Stream()
-            side_s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side_s):
-                gstep()
-                gstep()
-            torch.cuda.current_stream().wait_stream(side_s)
-            with torch.cuda.graph(gph):
-                gstep()
+            def capture(sign):
+                def gstep():
+                    return wl.sampler._step(wl.net, wl.x, cond_s, wl.stage, wl.df, wl.doc, wl.nested, wl.label, self_s,
+                                            coef_s, noise_s, sign, None)
+                gph = torch.cuda.CUDAGraph()
+                side_s = torch.cuda.Stream()
+                side_s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side_s):
+                    gstep()
+                    gstep()
+                torch.cuda.current_stream().wait_stream(side_s)
+                with torch.cuda.graph(gph):
+                    out = gstep()
+                return gph, out
+            graphs = {sign: capture(sign) for sign in sorted(set(wl.sign if is_lr else [False]))}
 
             def replay(first, n):
                 for i in range(first, first + n):
-                    cond_s.copy_(wl.cond[i % 200].expand(batch))
-                    coef_s.copy_(wl.coef[i % 200])
+                    j = i % 200
+                    cond_s.copy_(wl.cond[j].expand(batch))
+                    coef_s.copy_(wl.coef[j])
                     if noise_s is not None:
                         noise_s.normal_()
+                    gph, out = graphs[wl.sign[j] if is_lr else False]
                     gph.replay()
+                    if is_lr:
+                        self_s.copy_(out)
             replay(0, 2)
             torch.cuda.synchronize()
         except Exception as e:      # noqa: BLE001

@@ -854,291 +854,6 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
 }
 
 // ------------------------------------------------------------------------------------------------
-// Third geometry (bf16x3 only): 256 x 256 tiles, FOUR waves of 128 x 128 -- one wave per SIMD with the whole register
-// file (256 accumulator registers per lane), the shape vendor GEMMs use on this architecture.  Why: inside the k-loop
-// the 256 x 128 / 8-wave kernel above moves 176 KB through the LDS per k-step (1 408 clocks at 128 B/clk) against
-// 1 536 clocks of MFMA -- two pipes that are 92 % and 100 % busy do not overlap perfectly (measured 1 990).  A 128 x 128
-// wave tile reads 32 KB of fragments per 96 MFMAs instead of 16 KB per 24: per 256 x 128-equivalent k-step the LDS moves
-// 96 KB (768 clocks), half the MFMA time.  Two 64 KB stage buffers; the schedule is the 2-stage spliced one of the
-// 128-row geometry with every wait written as vmcnt(0) / lgkmcnt(0): a k-step is 3 072 MFMA clocks per SIMD, so the
-// reads of the next half step (issued between the first 16 MFMAs of the current one) and the DMA of tile it+2 (issued
-// in the second half of step it, needed at the middle of step it+1) have landed long before they are waited for.
-// Restrictions (host-checked): cout % 256 == 0, 16-B aligned epilogue operands; the epilogue is the shared one.
-namespace g3 {
-constexpr int BM = 256, BN = 256, MI = 4, NI = 4, WM = 2, WN = 2, THREADS = 256;
-constexpr int A_BYTES = BM * G2_LINE, B_BYTES = BN * G2_LINE, BUF = A_BYTES + B_BYTES;      // 64 KB per stage
-constexpr int TAB = 2 * BUF;                                                                // neighbour-table slice [BM][8] uint32
-constexpr int LDS = TAB + BM * 8 * 4;                                                       // 139 264 B
-constexpr int NDMA = 16;                                                                    // DMA instructions per wave per k-step
-constexpr int NREAD = 16;                                                                   // LDS reads per half step
-constexpr int NMFMA = 3 * MI * NI;                                                          // MFMAs per half step
-struct Half { bf16x8_t a[2][MI], b[2][NI]; };                                               // [0] = hi, [1] = lo
-struct Idx { uint32_t v[8]; };
-}  // namespace g3
-
-#define G3_HALF_OPS(F)                                                                                                 \
-  "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[0][2]), "+v"(F.a[0][3]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.a[1][2]), \
-      "+v"(F.a[1][3]), "+v"(F.b[0][0]), "+v"(F.b[0][1]), "+v"(F.b[0][2]), "+v"(F.b[0][3]), "+v"(F.b[1][0]),             \
-      "+v"(F.b[1][1]), "+v"(F.b[1][2]), "+v"(F.b[1][3])
-__device__ __forceinline__ void g3_wait_reads(g3::Half& F) {          // all LDS reads of this wave landed; guards F
-  asm volatile("s_waitcnt lgkmcnt(0)" : G3_HALF_OPS(F));
-}
-__device__ __forceinline__ void g3_wait_all_barrier(g3::Half& F) {    // + all DMA of this wave landed, then meet the block
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : G3_HALF_OPS(F)::"memory");
-}
-__device__ __forceinline__ void g3_wait_idx(g3::Idx& I) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(I.v[0]), "+v"(I.v[1]), "+v"(I.v[2]), "+v"(I.v[3]), "+v"(I.v[4]), "+v"(I.v[5]), "+v"(I.v[6]), "+v"(I.v[7]));
-}
-
-__global__ void __launch_bounds__(256) gconv3_kernel(const Gemm2Args a) {
-  using namespace g3;
-  extern __shared__ __attribute__((aligned(128))) char smem3[];
-  const GemmArgs& g = a.e;
-  const int ntile = g.ntm * g.ntn;
-  int bid = blockIdx.x;
-  {   // XCD-aware bijective tile order (as gconv2_kernel)
-    const int q = ntile / 8, r = ntile % 8, xcd = bid % 8, j = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  const int tm = bid / g.ntn, tn = bid - tm * g.ntn;
-  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
-  const int l31 = lane & 31, h = lane >> 5;
-  const bool dbg = a.dbg != nullptr;
-  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
-  if (dbg) ts0 = g2_clock();
-
-  // ---- neighbour-table slice -> LDS as unsigned 128-B line offsets (same encoding as gconv2_kernel)
-  const char* const xlo = a.xp < a.aux ? a.xp : a.aux;
-  {
-    uint32_t* tab = reinterpret_cast<uint32_t*>(smem3 + TAB);
-    const int64_t mmax = g.M - 1;
-    const int64_t lpr = a.ldx >> 7, lpt = a.ldt >> 7;
-    const int64_t x_line = (a.xp - xlo) >> 7, aux_line = (a.aux - xlo) >> 7;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int e = threadIdx.x + THREADS * t;
-      const int r = e >> 3, d = e & 7;
-      int64_t m = m0 + r;
-      m = m < mmax ? m : mmax;
-      int64_t line;
-      if (d < 7) {
-        const int64_t id = a.nbr_ext[m * 7 + d];
-        line = id < a.n_src ? x_line + id * lpr : aux_line + (id - a.n_src) * lpr;
-      } else {
-        line = m * lpt;
-      }
-      tab[e] = (uint32_t)line;
-    }
-  }
-  __syncthreads();
-  if (dbg) ts1 = g2_clock();
-
-  auto sgpr32 = [](int v) {
-    int r = __builtin_amdgcn_readfirstlane(v);
-    asm volatile("" : "+s"(r));
-    return r;
-  };
-  auto sgpr64 = [](uint64_t v) {
-    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    asm volatile("" : "+s"(lo), "+s"(hi));
-    return ((uint64_t)hi << 32) | lo;
-  };
-  const int64_t wstep = (int64_t)sgpr64((uint64_t)(g.N * (int64_t)G2_LINE));
-  const int tpd = sgpr32(a.tpd), nkt_g = sgpr32(a.nkt_g), nkt = sgpr32(a.nkt);
-  const gcp xp_s = (gcp)sgpr64((uint64_t)xlo), tfp_s = (gcp)sgpr64((uint64_t)a.tfp);
-  const unsigned lds0 = (unsigned)(uintptr_t)(ldsp)smem3;
-
-  // ---- per-lane DMA source state: wave w stages A rows / weight columns w*64 + j*8 + rsub (j < 8), piece q8 of the line,
-  // swizzled on the source side by (row >> 1) & 7 = (j*4 + (lane >> 4)) & 7
-  const int q8 = lane & 7, rsub = lane >> 3;
-  const int swz0 = (lane >> 4) & 7, swz1 = (4 + (lane >> 4)) & 7;
-  const int pa0 = (q8 ^ swz0) * 16, pa1 = (q8 ^ swz1) * 16;
-  const unsigned tab_lane = lds0 + TAB + (wid * 64 + rsub) * 32;          // + j*256 + column*4
-  const gcp wbE = (gcp)a.W2 + (n0 + wid * 64 + rsub) * G2_LINE + pa0;     // even j; odd j: + 8 columns, other swizzle
-  const gcp wbO = (gcp)a.W2 + (n0 + wid * 64 + 8 + rsub) * G2_LINE + pa1;
-
-  struct Tile { int tcol; int ktw; gcp base; };
-  Idx I;
-  auto load_idx = [&](const Tile& T) {
-    const unsigned ad = tab_lane + T.tcol * 4;
-    g2_ds_read32<0>(I.v[0], ad);    g2_ds_read32<256>(I.v[1], ad);  g2_ds_read32<512>(I.v[2], ad);  g2_ds_read32<768>(I.v[3], ad);
-    g2_ds_read32<1024>(I.v[4], ad); g2_ds_read32<1280>(I.v[5], ad); g2_ds_read32<1536>(I.v[6], ad); g2_ds_read32<1792>(I.v[7], ad);
-  };
-  auto issue_one = [&](const Tile& T, int ob, auto k_tag) {
-    constexpr int k = decltype(k_tag)::value;
-    if constexpr (k < 8) {
-      const gcp b = T.base + ((k & 1) ? pa1 : pa0);
-      __builtin_amdgcn_global_load_lds(b + ((uint64_t)I.v[k] << 7),
-                                       (ldsp)(smem3 + ob + wid * (64 * G2_LINE) + k * (8 * G2_LINE)), 16, 0, 0);
-    } else {
-      constexpr int j = k - 8;
-      __builtin_amdgcn_global_load_lds(((j & 1) ? wbO : wbE) + (j >> 1) * (16 * G2_LINE) + (int64_t)T.ktw * wstep,
-                                       (ldsp)(smem3 + ob + A_BYTES + wid * (64 * G2_LINE) + j * (8 * G2_LINE)), 16, 0, 0);
-    }
-  };
-  auto tile_of = [&](int it) {
-    Tile T;
-    if (it < nkt_g) {
-      const int chunk = it / 7, dir = it - chunk * 7;
-      T.tcol = dir; T.ktw = dir * tpd + chunk; T.base = xp_s + (int64_t)chunk * G2_LINE;
-    } else {
-      T.tcol = 7; T.ktw = it; T.base = tfp_s + (int64_t)(it - nkt_g) * G2_LINE;
-    }
-    return T;
-  };
-
-  // ---- fragment read addresses: piece class t of row l31 sits at ((2t + h) ^ s7) * 16; half c holds {hi, lo} of
-  // k 16c..16c+15 = classes c and 2 + c
-  const int s7 = (l31 >> 1) & 7;
-  unsigned fa[2][2], fb[2][2];
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int t = u == 0 ? c : 2 + c;
-      const int po = ((2 * t + h) ^ s7) * 16;
-      fa[c][u] = lds0 + (wm * 128 + l31) * G2_LINE + po;
-      fb[c][u] = lds0 + A_BYTES + (wn * 128 + l31) * G2_LINE + po;
-    }
-  auto read_one = [&](int ob, int c, Half& F, auto r_tag) {
-    constexpr int r = decltype(r_tag)::value;
-    if constexpr (r < 8) {
-      constexpr int u = r / 4, i = r % 4;
-      g2_ds_read128<i * 32 * G2_LINE>(F.a[u][i], fa[c][u] + ob);
-    } else {
-      constexpr int u = (r - 8) / 4, j = (r - 8) % 4;
-      g2_ds_read128<j * 32 * G2_LINE>(F.b[u][j], fb[c][u] + ob);
-    }
-  };
-  f32x16 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  auto mfma_one = [&](const Half& F, auto m_tag) {
-    constexpr int m = decltype(m_tag)::value;
-    constexpr int t = m / (MI * NI), i = (m / NI) % MI, j = m % NI;
-    // small cross terms first, the leading term last (same order as gconv2_kernel: results are bit-equal)
-    if constexpr (t == 0) acc[i][j] = g2_mfma<2>(F.a[1][i], F.b[0][j], acc[i][j]);
-    else if constexpr (t == 1) acc[i][j] = g2_mfma<2>(F.a[0][i], F.b[1][j], acc[i][j]);
-    else acc[i][j] = g2_mfma<2>(F.a[0][i], F.b[0][j], acc[i][j]);
-  };
-#define G3_FENCE() __builtin_amdgcn_sched_barrier(0)
-  Half F0, F1;
-  // MFMAs of Fc with the reads of the next half set Fr (stage ob_r, half c_r) between the first 16 of them and,
-  // optionally, the DMA request of tile T (16 instructions, after the table entries landed) between the later ones
-  auto half_step = [&](const Half& Fc, bool do_read, int ob_r, int c_r, Half& Fr, auto dma_tag, const Tile& T, int ob_dma) {
-    constexpr bool DMA = decltype(dma_tag)::value;
-    g2_static_for<NMFMA>([&](auto m_tag) {
-      constexpr int m = decltype(m_tag)::value;
-      mfma_one(Fc, m_tag);
-      if constexpr (m < NREAD) {
-        if (do_read) read_one(ob_r, c_r, Fr, m_tag);
-      }
-      if constexpr (DMA) {
-        if constexpr (m == NREAD) g3_wait_idx(I);
-        if constexpr (m > NREAD && m - NREAD - 1 < NDMA) issue_one(T, ob_dma, std::integral_constant<int, m - NREAD - 1>());
-      }
-      G3_FENCE();
-    });
-  };
-
-  // ---- prologue: tiles 0 and 1 requested, both landed for everyone, first half of tile 0 on its way to registers
-  {
-    const Tile T0 = tile_of(0);
-    load_idx(T0);
-    g3_wait_idx(I);
-    g2_static_for<NDMA>([&](auto k_tag) { issue_one(T0, 0, k_tag); });
-  }
-  if (nkt > 1) {
-    const Tile T1 = tile_of(1);
-    load_idx(T1);
-    g3_wait_idx(I);
-    g2_static_for<NDMA>([&](auto k_tag) { issue_one(T1, BUF, k_tag); });
-  }
-  g2_wait_barrier<0>();
-  if (dbg) ts2 = g2_clock();
-  g2_static_for<NREAD>([&](auto r_tag) { read_one(0, 0, F0, r_tag); });
-
-  int ob = 0, obn = BUF;
-  int it = 0, gd = 2, gc = 0;
-  if (nkt_g <= 2) { gd = 0; gc = 0; }                                   // (never: nkt_g >= 7)
-  auto next_tile = [&]() {                                              // tile it + 2, advanced without division
-    const int ti = it + 2;
-    const bool gat = ti < nkt_g;
-    Tile T;
-    T.tcol = gat ? gd : 7;
-    T.ktw = gat ? gd * tpd + gc : ti;
-    T.base = (gat ? xp_s : tfp_s) + (int64_t)(gat ? gc : ti - nkt_g) * G2_LINE;
-    const int wrap = gd == 6;
-    gd = wrap ? 0 : gd + 1;
-    gc += wrap;
-    return T;
-  };
-  for (; it + 2 < nkt; ++it) {
-    const Tile T = next_tile();
-    g3_wait_reads(F0);
-    G3_FENCE();
-    half_step(F0, true, ob, 1, F1, std::false_type(), T, 0);
-    g3_wait_all_barrier(F1);          // everyone finished reading `ob`; everyone's part of tile it+1 landed
-    G3_FENCE();
-    load_idx(T);
-    half_step(F1, true, obn, 0, F0, std::true_type(), T, ob);
-    const int t = ob; ob = obn; obn = t;
-  }
-  {
-    const Tile Tn = {};
-    if (it + 1 < nkt) {               // second to last tile: nothing left to request
-      g3_wait_reads(F0);
-      G3_FENCE();
-      half_step(F0, true, ob, 1, F1, std::false_type(), Tn, 0);
-      g3_wait_all_barrier(F1);
-      G3_FENCE();
-      half_step(F1, true, obn, 0, F0, std::false_type(), Tn, 0);
-      const int t = ob; ob = obn; obn = t;
-      ++it;
-    }
-    g3_wait_reads(F0);                // last tile
-    G3_FENCE();
-    half_step(F0, true, ob, 1, F1, std::false_type(), Tn, 0);
-    g3_wait_reads(F1);
-    G3_FENCE();
-    half_step(F1, false, 0, 0, F0, std::false_type(), Tn, 0);
-  }
-#undef G3_FENCE
-  if (dbg) ts3 = g2_clock();
-  if (g.vec4) epilogue_store_v4<WM, WN, MI, NI>(g, acc, m0, n0, wm, wn, l31, h);
-  else epilogue_store_scalar<WM, WN, MI, NI>(g, acc, m0, n0, wm, wn, l31, h, 0);
-  if (dbg) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long ts4 = g2_clock();
-    if (threadIdx.x == 0) {
-      unsigned long long* o = a.dbg + (size_t)blockIdx.x * 8;
-      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = ts4;
-      o[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-    }
-  }
-}
-
-static int g3_launch(Gemm2Args& a, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            g3::LDS) != hipSuccess)
-      return OFX_ELAUNCH;
-    attr_set = true;
-  }
-  gconv3_kernel<<<a.e.ntm * a.e.ntn, g3::THREADS, g3::LDS, st>>>(a);
-  return OFX_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
 // plane conversion helpers
 __device__ __forceinline__ unsigned g2_pk_bf16(float a, float b) {
   unsigned r;
@@ -1392,7 +1107,7 @@ extern "C" int ofx_set_gconv2_prefetch(int on) {
   return OFX_OK;
 }
 extern "C" int ofx_set_gconv2_tile(int wm) {
-  if (wm != 0 && wm != 1 && wm != 2 && wm != 4 && wm != 8) return OFX_EINVAL;   // 1: automatic without the long-tensor rule (A/B); 8: 256 x 256 / 4-wave kernel where eligible
+  if (wm != 0 && wm != 1 && wm != 2 && wm != 4) return OFX_EINVAL;     // 1: the plain width rule (A/B of the automatic choice)
   g2_wm = wm;
   return OFX_OK;
 }
@@ -1449,20 +1164,6 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
   // (blocks do not run in lock-step rounds, and the second launch pays its own fill and drain) --
   // profiles/r02/gconv2_geometry.txt.
   int rc = OFX_OK;
-  if (g2_wm == 8 && mode == 2 && cout % 256 == 0 && g.vec4 && a.nkt >= 2) {
-    // 256 x 256 tiles, four waves of 128 x 128 (gconv3_kernel)
-    a.row0 = 0;
-    g.ntm = (int)ofx_cdiv(g.M, 256);
-    g.ntn = cout / 256;
-    rc = g3_launch(a, st);
-    if (rc) return rc;
-    if (g.stats_part) {
-      rc = ofx_launch_stats_reduce(g, 128, st);
-      if (rc) return rc;
-    }
-    OFX_LAUNCH_CHECK();
-    return OFX_OK;
-  }
 #define G2_GO(P_, V_, WM_)                                                                            \
   (ni == 1 ? (WM_ == 4 ? g2_launch<P_, V_, 4, 1>(a, st) : g2_launch<P_, V_, 2, 1>(a, st))             \
            : (WM_ == 4 ? g2_launch<P_, V_, 4, 2>(a, st) : g2_launch<P_, V_, 2, 2>(a, st)))
@@ -1489,7 +1190,15 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
   // narrow layers on very long tensors (depth 7 / 8 of the feature net: >= 8 rounds of 256-row tiles) amortise the
   // prologue better with the 256-row geometry too: 2-5 % (tools/gconv2_tile_d8.py)
   const int64_t tiles4 = ofx_cdiv(g.M, 256) * g.ntn;
-  rc = launch((g2_wm == 2 || g2_wm == 4) ? g2_wm : ((cout <= 128 && (tiles4 < 2048 || g2_wm == 1)) ? 2 : 4), 0, g.M);
+  // wide layers whose 256-row tiles leave a small last round (depth 5 of the jittered shell-6 batch: 530 tiles on 256
+  // CUs) pay a whole big-tile time for it; the same rows as 128-row tiles pay a small-tile time: 2-10 %
+  // (profiles/r02/gconv2_geometry.txt, d5 256->256 / 512->256 / 768->256)
+  const int64_t tail4 = tiles4 % 256;
+  const bool small_tail = tail4 > 0 && tail4 <= 64 && tiles4 < 1536;
+  int wm_auto = (cout <= 128 && tiles4 < 2048) ? 2 : 4;
+  if (cout > 128 && small_tail) wm_auto = 2;
+  if (g2_wm == 1) wm_auto = cout <= 128 ? 2 : 4;                       // A/B: the plain width rule
+  rc = launch((g2_wm == 2 || g2_wm == 4) ? g2_wm : wm_auto, 0, g.M);
 #undef G2_GO
   if (rc) return rc;
   if (g.stats_part) {

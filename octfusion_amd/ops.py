@@ -222,8 +222,10 @@ def side_stream(device):
 
 
 def workspace(device, nbytes=64 << 20):
-    """Per-(device, stream) split-K scratch (partial tiles); reused by every launch on that stream."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
+    """Per-device split-K scratch (partial tiles); reused by every launch -- launches are ordered on one stream.  Only
+    with the side-stream experiment on (two streams run concurrently) it is kept per stream."""
+    sid = torch.cuda.current_stream(device).cuda_stream if (SIDE_STREAM and device.type == 'cuda') else 0
+    key = (device.type, device.index, sid)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(nbytes, dtype=torch.uint8, device=device)

@@ -453,6 +453,9 @@ int ofx_gn_fused_rows(const float* x, int64_t ldx, int rows_per_batch, int batch
                       float count_eps, const float* w, const float* bias, int act, float* out, int64_t ldo,
                       void* stream);
 
+/* A/B knob: 1 (default) = 16-channel blocks for ofx_gn_fused_rows where the shape allows, 0 = one block per group */
+int ofx_set_gn_rows16(int on);
+
 /* ---------------------------------------------------------------- glue ops */
 /* dst[dmap(i), 0:C] = src[smap(i), 0:C] for i < n (maps optional; negative skips). */
 int ofx_rows_copy(const float* src, int64_t lds, const int32_t* smap, float* dst, int64_t ldd,

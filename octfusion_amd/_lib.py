@@ -74,6 +74,7 @@ _SIGS = {
     'ofx_adamw_step': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_p], True),
     'ofx_ema_update': (c_i, [c_p, c_p, c_l, c_f, c_p], True),
     'ofx_gn_fused_rows': (c_i, [c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_i, c_p, c_l, c_p], True),
+    'ofx_set_gn_rows16': (c_i, [c_i], True),
     'ofx_mpu_eval': (c_i, [ctypes.POINTER(OfxTree), c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p], True),
     'ofx_mpu_eval_grid': (c_i, [ctypes.POINTER(OfxTree), c_i, c_i, c_p, c_i, c_f, c_f, c_i, c_l, c_l, c_p, c_p, c_p], True),
     'ofx_mpu_eval_grad': (c_i, [ctypes.POINTER(OfxTree), c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p], True),

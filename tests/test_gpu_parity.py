@@ -1153,3 +1153,34 @@ def test_incremental_dual_octree(golden):
     # an unrelated octree adopts nothing
     other = split2octree_small(C.shell6_split(2, jitter=True).to(dev()), 6, 4)
     assert DualOctree(other, prev=doc6).adopted_depths == []
+
+
+@pytest.mark.gpu
+def test_gn_fused_rows_mappings():
+    """One-launch GroupNorm of the dense grids: the 16-channel block mapping (C = 64 .. 512) equals the one-block-per-group
+    mapping and torch.nn.functional.group_norm; odd widths (cpg 6 / 12: concatenated inputs) and short grids stay on the
+    per-group kernel; strided input / output (column slices of wider buffers)."""
+    import torch.nn.functional as F
+    from octfusion_amd import _lib, ops
+    g = torch.Generator().manual_seed(9)
+    for B, rows, C in [(3, 4096, 64), (2, 4096, 128), (2, 2048, 256), (1, 2304, 512), (2, 4096, 192), (2, 512, 256), (2, 64, 256), (1, 1000, 64)]:
+        x_wide = torch.randn(B * rows, C + 32, generator=g).to(dev())
+        x = x_wide[:, 16:16 + C]                                  # strided rows, 64-B aligned start
+        w = torch.randn(C, generator=g).to(dev())
+        b = torch.randn(C, generator=g).to(dev())
+        bid = torch.arange(B).repeat_interleave(rows).to(torch.int32).to(dev())
+        cnt = torch.full((B,), float(rows), device=dev())
+        outs = {}
+        for knob in (1, 0):
+            _lib.call('ofx_set_gn_rows16', knob)
+            out_wide = torch.zeros(B * rows, C + 8, device=dev())
+            y = ops.group_norm(x, bid, cnt, B, w, b, 32, eps=1e-5, act='silu', out=out_wide[:, 4:4 + C], count_eps=0.0,
+                               rows_per_batch=rows)
+            outs[knob] = y.clone()
+            assert float(out_wide[:, :4].abs().max()) == 0.0 and float(out_wide[:, 4 + C:].abs().max()) == 0.0
+        _lib.call('ofx_set_gn_rows16', 1)
+        ref = F.silu(F.group_norm(x.view(B, rows, C).transpose(1, 2).contiguous().cpu().double(), 32, w.cpu().double(),
+                                  b.cpu().double(), 1e-5)).transpose(1, 2).reshape(B * rows, C).float()
+        close(outs[1], ref, 2e-5)
+        close(outs[0], ref, 2e-5)
+        close(outs[1], outs[0], 2e-6)

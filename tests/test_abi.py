@@ -41,6 +41,17 @@ def test_product_fails_loudly_without_gpu():
         split2octree_small(torch.zeros(1, 8, 4, 4, 4), 4, 2)
     with pytest.raises(_lib.OfxError):
         ops.gather_mean(torch.zeros(4, 4), torch.zeros(29, dtype=torch.int32), torch.zeros(1, dtype=torch.int32))
+    # training side: losses, NeuralMPU gradient, point-cloud build have no CPU path either
+    from octfusion_amd import vae_training as VT
+    from octfusion_amd.octree import Points, build_octree_batch
+    with pytest.raises(_lib.OfxError):
+        VT.octree_ce(torch.zeros(4, 2), torch.zeros(4, dtype=torch.int32))
+    with pytest.raises(_lib.OfxError):
+        VT.sdf_reg_loss(torch.zeros(4), torch.zeros(4, 3), torch.zeros(4), torch.zeros(4, 3))
+    with pytest.raises(_lib.OfxError):
+        VT.kl_sample(torch.zeros(4, 6), torch.zeros(4, 3), 3)
+    with pytest.raises(_lib.OfxError):
+        build_octree_batch([Points(torch.zeros(8, 3), torch.zeros(8, 3))], 6, 4)
 
 
 def test_product_never_imports_oracle():

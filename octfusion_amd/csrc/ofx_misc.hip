@@ -17,8 +17,10 @@ extern "C" const char* ofx_status_string(int status) {
 extern "C" int ofx_device_check(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return OFX_ENODEV;
+  int cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return OFX_ENODEV;          // the calling process's device (one rank per GPU)
   hipDeviceProp_t p;
-  if (hipGetDeviceProperties(&p, 0) != hipSuccess) return OFX_ENODEV;
+  if (hipGetDeviceProperties(&p, cur) != hipSuccess) return OFX_ENODEV;
   const char* a = p.gcnArchName;
   for (int i = 0; a[i]; ++i)
     if (a[i] == 'g' && a[i + 1] == 'f' && a[i + 2] == 'x' && a[i + 3] == '9' && a[i + 4] == '5' && a[i + 5] == '0')

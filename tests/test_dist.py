@@ -125,3 +125,25 @@ def test_gradient_all_reduce_world2(tmp_path):
     mp.spawn(_grad_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     r = torch.load(out)
     assert r['ok'] and r['nbytes'] == 4 * r['numel']
+
+
+def test_committed_bench_lines_follow_the_contract():
+    """the four bench lines committed under profiles/r02 carry every field the bench contract names (they are the
+    output of bench.py on the GPU box; this guards the schema against drift)."""
+    import json
+    for wl in ('hr', 'lr', 'hr_cond', 'feature'):
+        line = json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'bench_r02_%s.json' % wl)))
+        for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                  'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+            assert k in line, (wl, k)
+        assert line['n_gpus'] == 1 and line['higher_is_better'] is True and line['scaling'] == 'weak'
+        assert line['vs_baseline'] is None and line['data'] == 'synthetic' and 'workload' in line['config']
+        assert abs(line['value'] - 1e3 / line['ms_per_step']) <= 1e-6 * line['value']
+        r = line['roofline']
+        for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+            assert k in r, (wl, k)
+        assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+        c = line['cpu_baseline']
+        for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+            assert k in c, (wl, k)
+        assert c['kind'] in ('port', 'reference')

@@ -39,6 +39,11 @@ int ofx_version(void);
 const char* ofx_status_string(int status);
 /* 0 when a HIP device is present and is gfx950; OFX_ENODEV otherwise. */
 int ofx_device_check(void);
+/* sha256 (16 hex digits) of every source, header and compile flag this library was built from
+ * (octfusion_amd/build.py); the Python binding refuses a library whose hash differs from the tree.
+ * ofx_build_ablation: 1 for a -DOFX_ABLATION build (timing ablations compiled in), 0 for a product build. */
+const char* ofx_build_hash(void);
+int ofx_build_ablation(void);
 
 /* ------------------------------------------------------------------ scans */
 /* Exclusive prefix sum of n int32 values into out[0..n] (out[n] = total).
@@ -353,9 +358,18 @@ int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes,
  *      [k tile][cout][128-B line], k order: 7*cin gathered channels direction-major, then the 7*nt node-type
  *      rows zero-padded to a whole tile; ofx_planes_packed_bytes() bytes.
  * ofx_graphconv_fwd_planes: as ofx_graphconv_fwd, with xp / aux / tfp planes (row pitches in BYTES, 128-B
- *      aligned bases and pitches), aux = scratch of (n_multi + 1) rows of ldx_bytes, tfp = planes of the
+ *      aligned bases and pitches), aux = scratch of aux_bytes >= (n_multi + 1) * ldx_bytes, tfp = planes of the
  *      type_frac slab padded to a whole chunk (NULL when nt <= 1), W2 = packed planes weights.
- *      256 x 128 tiles, no split-K: meant for layers with >= ~128 tiles. */
+ *      Two launch shapes (csrc/ofx_gemm3.hip, csrc/ofx_gemm2.hip):
+ *      - persistent stream-K blocks (default when `sync` is given and the layer has >= 64 k-step units): as many
+ *        blocks as the device holds at once, each owning an equal contiguous share of the (tile, k-step) sequence;
+ *        tiles cut by a share boundary are combined in-launch through `ws` (raw fp32 accumulator pieces behind the
+ *        statistics partials: <= (CUs * 2) * 64 KB) and `sync`: >= (2 * CUs + 1) uint32, ZERO on the first call,
+ *        left zero by every launch; word [blocks] is a sticky error flag (a bounded wait gave up).  nbr_ext needs
+ *        16 B of readable slack behind its last entry and a 16-B aligned base.  Deterministic: the pieces of a tile
+ *        are added in ascending k order.
+ *      - one tile per block (sync == NULL, tiny layers, ofx_set_gconv_persistent(0)): 256 / 128 x 128 tiles, no
+ *        split-K, meant for layers with >= ~128 tiles. */
 int ofx_planes_split(const float* x, int64_t ldx, int64_t n, int C, int Cpad, int mode, void* out,
                      int64_t ldo_bytes, void* stream);
 int ofx_planes_merge(const void* planes, int64_t ldp_bytes, int64_t n, int C, int mode, float* out, int64_t ldo,
@@ -370,13 +384,18 @@ int ofx_pack_weights_planes(const float* W, int64_t sk, int64_t sn, int cin, int
                             void* stream);
 int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int cin, int64_t n_nodes, const int32_t* seg_ptr,
                              const int32_t* col, const int32_t* nbr_ext, const int32_t* multi_seg, int64_t n_multi,
-                             void* aux, const void* tfp, int64_t ldt_bytes, int nt, const void* W2, int cout,
-                             const float* bias, const float* emb, int64_t lde, const int32_t* batch_id,
+                             void* aux, size_t aux_bytes, const void* tfp, int64_t ldt_bytes, int nt, const void* W2,
+                             int cout, const float* bias, const float* emb, int64_t lde, const int32_t* batch_id,
                              const float* res, int64_t ldr, float* out, int64_t ldc, double* stats /* optional */,
-                             int64_t stats_ld, void* ws, size_t ws_bytes, int mode, int aux_ready, void* stream);
-/* scheduling variant of the planes kernel: 5 (default) = LDS reads and DMA requests spliced between the MFMAs,
- * 1 = DMA requests interleaved by the compiler's sched_group_barrier, 0 = requests before the MFMA group;
- * 2, 3, 4, 6 = timing ablations with WRONG results (no MFMA / no DMA / no fragment reads / no barrier) -- A/B knob */
+                             int64_t stats_ld, void* ws, size_t ws_bytes, void* sync /* optional */, size_t sync_bytes,
+                             int mode, int aux_ready, void* stream);
+/* 1 (default): persistent stream-K launch where the shape qualifies; 0: always one tile per block -- A/B knob */
+int ofx_set_gconv_persistent(int on);
+/* scheduling variant of the one-tile-per-block planes kernel: 5 = LDS reads and DMA requests spliced between the
+ * MFMAs -- the only one a product build contains (anything else: OFX_EINVAL).  Builds with -DOFX_ABLATION
+ * (python -m octfusion_amd.build --ablation) also hold 1 = DMA requests interleaved by sched_group_barrier,
+ * 0 = requests before the MFMA group, and 2, 3, 4, 6 = timing ablations with WRONG results (no MFMA / no DMA /
+ * no fragment reads / no barrier). */
 int ofx_set_gconv2_variant(int v);
 /* block geometry of the planes kernel: 0 = automatic, 2 = 128 x 128 tiles (4 waves, two blocks per CU),
  * 4 = 256 x 128 tiles (8 waves, one block per CU) -- A/B knob */
@@ -385,7 +404,7 @@ int ofx_set_gconv2_tile(int wm);
  * layer; 0 = start together -- A/B knob */
 int ofx_set_gconv2_stagger(int clocks_per_ktile);
 int ofx_set_gconv2_prefetch(int on);   /* 1 (default): block b pulls the table slice of block b + resident blocks into L2 */
-/* profiling aid: when buf != NULL every block of the following ofx_graphconv_fwd_planes launches writes 8 uint64
+/* profiling aid (-DOFX_ABLATION builds only; a product build accepts NULL only): when buf != NULL every block of the following ofx_graphconv_fwd_planes launches writes 8 uint64
  * to buf[block*8..]: shader-clock stamps at start / table built / first tile landed / k-loop done / stores drained,
  * then HW_ID.  buf must hold 8 * (tiles of the largest launch) uint64.  NULL switches it off. */
 int ofx_set_gconv2_debug(void* buf);

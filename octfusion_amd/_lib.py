@@ -30,6 +30,8 @@ _SIGS = {
     'ofx_version': (c_i, [], False),
     'ofx_status_string': (ctypes.c_char_p, [c_i], False),
     'ofx_device_check': (c_i, [], False),
+    'ofx_build_hash': (ctypes.c_char_p, [], False),
+    'ofx_build_ablation': (c_i, [], False),
     'ofx_scan_ws_bytes': (c_sz, [c_l], False),
     'ofx_scan_i32': (c_i, [c_p, c_p, c_l, c_p, c_p], True),
     'ofx_octree_full_layer': (c_i, [c_i, c_i, c_p, c_p, c_p], True),
@@ -102,8 +104,10 @@ _SIGS = {
     'ofx_planes_packed_ktiles': (c_l, [c_i, c_i, c_i], False),
     'ofx_planes_packed_bytes': (c_l, [c_i, c_i, c_i, c_i], False),
     'ofx_pack_weights_planes': (c_i, [c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_p], True),
-    'ofx_graphconv_fwd_planes': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_i,
-                                       c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_sz, c_i, c_i, c_p], True),
+    'ofx_graphconv_fwd_planes': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_sz, c_p, c_l, c_i, c_p, c_i,
+                                       c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_sz, c_p, c_sz, c_i, c_i,
+                                       c_p], True),
+    'ofx_set_gconv_persistent': (c_i, [c_i], True),
     'ofx_set_gconv2_variant': (c_i, [c_i], True),
     'ofx_set_gconv2_debug': (c_i, [c_p], True),
     'ofx_set_gconv2_tile': (c_i, [c_i], True),
@@ -151,8 +155,25 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        _check_fresh(L)
         _lib = L
     return _lib
+
+
+def _check_fresh(L):
+    """Refuse a library that was not built from the sources next to it (libofx.so is git-ignored and mtime says
+    nothing after a checkout / snapshot): the build embeds the sha256 of every source, header and flag."""
+    if 'OFX_LIB' in os.environ:            # an explicitly chosen experiment build
+        return
+    from . import build
+    try:
+        want = {build.source_hash(), build.source_hash(build.FLAGS + ['-DOFX_ABLATION'])}
+    except OSError:
+        return                             # sources not shipped: nothing to compare with
+    have = L.ofx_build_hash().decode()
+    if have not in want:
+        raise OfxError('libofx.so is stale: built from sources %s, the tree is %s -- run `python -m octfusion_amd.build`'
+                       % (have, sorted(want)[0] if len(want) == 1 else build.source_hash()))
 
 
 def call(name, *args):

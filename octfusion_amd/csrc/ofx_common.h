@@ -14,6 +14,18 @@ static inline hipStream_t ofx_stream(void* s) { return reinterpret_cast<hipStrea
 
 static inline int64_t ofx_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: a process that launches on a second GPU
+// must set it there too.  `done` is the caller's per-kernel flag array.  Returns false on failure.
+constexpr int OFX_MAX_DEVICES = 64;
+static inline bool ofx_raise_lds_limit(const void* kernel, int bytes, bool (&done)[OFX_MAX_DEVICES]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= OFX_MAX_DEVICES) return false;
+  if (done[dev]) return true;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  done[dev] = true;
+  return true;
+}
+
 // grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8.
 static inline int ofx_grid(int64_t work_items, int block) {
   int64_t g = ofx_cdiv(work_items, block);

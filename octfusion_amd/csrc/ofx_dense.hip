@@ -189,13 +189,9 @@ static int launch_attention(const float* qkv, int64_t ldq, int B, int T, int hea
   const int Tp = (T + 31) & ~31;
   const size_t lds = (size_t)2 * Tp * (CH + 4) * sizeof(float);
   if (lds > 160 * 1024) return OFX_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_kernel<CH>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return OFX_ELAUNCH;
-    attr_set = true;
-  }
+  static bool attr_set[OFX_MAX_DEVICES] = {};
+  if (!ofx_raise_lds_limit(reinterpret_cast<const void*>(&attention_mfma_kernel<CH>), 160 * 1024, attr_set))
+    return OFX_ELAUNCH;
   dim3 grid((unsigned)(B * heads), (unsigned)ofx_cdiv(T, 128));
   attention_mfma_kernel<CH><<<grid, 256, lds, st>>>(qkv, ldq, T, heads, ch, out, ldo);
   return OFX_OK;

@@ -946,13 +946,10 @@ template <int MODE, int WM, int WN, int MI, int NI>
 static int launch_cfg(GemmArgs& g, hipStream_t st) {
   constexpr int BN = WN * NI * 32;
   constexpr size_t lds = (2 * BM * A_LD + 2 * 8 * BN * 4) * sizeof(float);
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {     // 68 KB for BN = 128: above the 64 KB default cap
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, WM, WN, MI, NI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return OFX_ELAUNCH;
-    attr_set = true;
-  }
+  static bool attr_set[OFX_MAX_DEVICES] = {};
+  if (lds > 64 * 1024 &&      // e.g. 68 KB for BN = 128: above the 64 KB default cap
+      !ofx_raise_lds_limit(reinterpret_cast<const void*>(&gemm_kernel<MODE, WM, WN, MI, NI>), (int)lds, attr_set))
+    return OFX_ELAUNCH;
   gemm_kernel<MODE, WM, WN, MI, NI><<<g.ntm * g.ntn * g.nsplit, 256, lds, st>>>(g);
   return OFX_OK;
 }
@@ -961,13 +958,10 @@ template <int MODE, int WM, int WN, int MI, int NI>
 static int launch_fast_cfg(GemmArgs& g, hipStream_t st) {
   constexpr int BN = WN * NI * 32;
   constexpr size_t lds = (2 * BM * A_LD + 2 * 8 * BN * 4) * sizeof(float);
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<MODE, WM, WN, MI, NI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return OFX_ELAUNCH;
-    attr_set = true;
-  }
+  static bool attr_set[OFX_MAX_DEVICES] = {};
+  if (lds > 64 * 1024 &&      // e.g. 68 KB for BN = 128: above the 64 KB default cap
+      !ofx_raise_lds_limit(reinterpret_cast<const void*>(&gemm_fast_kernel<MODE, WM, WN, MI, NI>), (int)lds, attr_set))
+    return OFX_ELAUNCH;
   gemm_fast_kernel<MODE, WM, WN, MI, NI><<<g.ntm * g.ntn * g.nsplit, 256, lds, st>>>(g);
   return OFX_OK;
 }
@@ -976,13 +970,10 @@ template <int MODE, int WM, int WN, int MI, int NI>
 static int launch_bf16x3_cfg(GemmArgs& g, hipStream_t st) {
   constexpr int BN = WN * NI * 32;
   constexpr size_t lds = 2 * (2 * BM * 80);
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<MODE, WM, WN, MI, NI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return OFX_ELAUNCH;
-    attr_set = true;
-  }
+  static bool attr_set[OFX_MAX_DEVICES] = {};
+  if (lds > 64 * 1024 &&      // e.g. 68 KB for BN = 128: above the 64 KB default cap
+      !ofx_raise_lds_limit(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<MODE, WM, WN, MI, NI>), (int)lds, attr_set))
+    return OFX_ELAUNCH;
   gemm_bf16x3_kernel<MODE, WM, WN, MI, NI><<<g.ntm * g.ntn * g.nsplit, 256, lds, st>>>(g);
   return OFX_OK;
 }

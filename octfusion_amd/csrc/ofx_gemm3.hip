@@ -1,0 +1,644 @@
+// libofx: fused dual-octree GraphConv on operand planes, PERSISTENT stream-K blocks (round 3).
+//
+// Same data path as ofx_gemm2.hip (operand planes, LDS-DMA staging with a source-side swizzle, hand-counted waits,
+// bf16x3 / fp16 MFMA, two-phase epilogue) -- what changes is who computes what:
+//   * the launch is exactly as many blocks as the chip holds at once (G = CUs x blocks per CU); the k-steps of ALL
+//     tiles form one sequence of U = tiles x nkt units and block b owns the contiguous range [bound(b), bound(b+1))
+//     ("stream-K"): every block does the same amount of MFMA work whatever the tile count, so the 3.31 -> 4 round
+//     quantisation of the one-tile-per-block launch (17 % on the depth-6 128 -> 128 layer, 31 % on depth 5) is gone;
+//   * a block walks its range tile by tile WITHOUT leaving the k-loop pipeline: the neighbour-table slice of the next
+//     row tile is fetched by one LDS-DMA per wave at the start of the current tile and converted to line offsets
+//     inside the last steady k-step; the two drain k-steps of a tile -- which had nothing to request -- request the
+//     first two k tiles of the NEXT tile, so their gather latency runs under the epilogue's stores.  Table build,
+//     first-DMA wait and store drain are paid once per block instead of once per tile;
+//   * a range boundary inside a tile splits that tile between neighbouring blocks.  The block that owns the tile's
+//     k = 0 end is its FINISHER: it runs the epilogue.  Every other contributor handles its piece FIRST, writes the raw
+//     accumulators to its own 64 / 128 KB slot of the workspace with write-through (sc1) stores, drains, and raises
+//     its flag; the finisher meets the tile LAST, adds the pieces in ascending k order (deterministic), resets the
+//     flags.  Hand-off protocol = cdna_hip_programming.md section 6 Guideline 16 R1 (sc1 payload -> every wave
+//     vmcnt(0) -> barrier -> one relaxed agent-scope flag store | one lane polls relaxed -> ONE agent-scope acquire ->
+//     barrier -> plain loads).  No block ever waits on a block that can itself be waiting (contributors' pieces are
+//     their first work item and depend on nothing), so the launch cannot deadlock as long as blocks are dispatched in
+//     index order; a spin is bounded all the same and reports through flags[G].
+// Range boundaries are snapped so that no piece is shorter than G3_KMIN k-steps: the loop shape is always
+// {steady..., last steady (requests the epilogue operands), drain A, drain B}.
+#include "ofx_planes.h"
+
+constexpr int G3_KMIN = 4;
+
+template <int WM, int NI> struct G3Cfg : G2Cfg<WM, NI> {
+  typedef G2Cfg<WM, NI> B;
+  static constexpr int TAB = B::NBUF * B::BUF;          // table of the CURRENT row tile: [BM][8] uint32 line offsets
+  static constexpr int RAW = TAB + B::BM * 32;          // raw nbr_ext slice of the NEXT row tile: BM x 7 int32; every
+  static constexpr int RAW_WAVE = 32 * 28;              //   wave lands 1 KB at a 896-B pitch (+128 B overrun at the end)
+  static constexpr int LDS = RAW + B::BM * 28 + 128;    // 162 944 B (WM 4) / 73 344 B (WM 2) / 56 960 B (WM 2, NI 1)
+};
+
+struct Gemm3Args {
+  Gemm2Args b;
+  int G;                       // blocks; a multiple of 8
+  unsigned q, rem;             // bound(lb) = lb * q + min(lb, rem), then snapped
+  unsigned U;                  // tiles * nkt
+  float* part;                 // [G][BM * BN] raw accumulator pieces
+  unsigned* flags;             // [G + 1], zero on entry and on exit; flags[G] != 0: a spin gave up
+  const char* nbr_lim;         // last 16-B aligned address inside nbr_ext that may be read
+};
+
+__device__ __forceinline__ void g3_ds_write32(unsigned addr, unsigned v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void g3_store128_sc1(void* p, g2_v4f v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+struct G3Raw { uint32_t v[4]; };
+__device__ __forceinline__ void g3_wait_lgkm0(G3Raw& R) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.v[0]), "+v"(R.v[1]), "+v"(R.v[2]), "+v"(R.v[3])::"memory");
+}
+
+template <int PREC, int WM, int NI>
+__global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
+  typedef G2Half<PREC, NI> Half;
+  typedef G3Cfg<WM, NI> CF;
+  constexpr int G2_NI = NI, G2_BN = CF::BN, G2_EPI_LOADS = CF::EPI_LOADS, RH = CF::READS;
+  constexpr int G2_WM = WM, G2_BM = CF::BM, G2_A_BYTES = CF::A_BYTES, G2_BUF = CF::BUF, G2_TAB = CF::TAB;
+  constexpr int GLDS = CF::GLDS;
+  extern __shared__ __attribute__((aligned(128))) char smem3[];
+  const Gemm2Args& a = A.b;
+  const GemmArgs& g = a.e;
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const bool dbg = a.dbg != nullptr;
+  unsigned long long ts0 = 0, ts1 = 0;
+  int dbg_piece = 0;
+  if (dbg) ts0 = g2_clock();
+
+  // ---- wave-uniform operands pinned in SGPRs (a kernarg s_load sunk into the loop would mix SMEM events into the
+  // hand-counted lgkmcnt waits)
+  auto sgpr32 = [](int v) {
+    int r = __builtin_amdgcn_readfirstlane(v);
+    asm volatile("" : "+s"(r));
+    return r;
+  };
+  auto sgpr64 = [](uint64_t v) {
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return ((uint64_t)hi << 32) | lo;
+  };
+  const char* const xlo = a.xp < a.aux ? a.xp : a.aux;
+  const int64_t wstep = (int64_t)sgpr64((uint64_t)(g.N * (int64_t)G2_LINE));   // bytes per k tile of the packed weights
+  const int tpd = sgpr32(a.tpd), nkt_g = sgpr32(a.nkt_g), nkt = sgpr32(a.nkt);
+  const gcp xp_s = (gcp)sgpr64((uint64_t)xlo), tfp_s = (gcp)sgpr64((uint64_t)a.tfp);
+  // (operands used once per piece -- table fetch / conversion, the stream-K bookkeeping -- stay kernel arguments: the
+  // compiler's own s_load + wait there costs nothing measurable and SGPRs are the scarce resource of this kernel)
+  const gcp nbr_s = (gcp)a.nbr_ext, lim_s = (gcp)A.nbr_lim;
+  const int ntn = g.ntn;
+  const int64_t Mrows = g.M;
+  const int n_src = (int)a.n_src;
+  const int lpr = (int)(a.ldx >> 7), lpt = (int)(a.ldt >> 7);                           // 128-B lines per row
+  const unsigned x_line = (unsigned)((a.xp - xlo) >> 7), aux_line = (unsigned)((a.aux - xlo) >> 7);
+  const unsigned lds0 = (unsigned)(uintptr_t)(ldsp)smem3;    // LDS byte address of the dynamic segment
+
+  // ---- this block's unit range.  Logical block id: XCD x (= blockIdx % 8 in dispatch order; speed only) owns the
+  // contiguous logical range [x * G/8, (x + 1) * G/8), i.e. contiguous row tiles share one L2.
+  const int G = A.G;
+  const unsigned sk_q = A.q, sk_rem = A.rem;
+  float* const part_s = A.part;
+  unsigned* const flags_s = A.flags;
+  const int lb = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
+  auto bound = [&](int b) -> unsigned {
+    unsigned u = (unsigned)b * sk_q + ((unsigned)b < sk_rem ? (unsigned)b : sk_rem);
+    unsigned t = u / (unsigned)nkt, r = u - t * (unsigned)nkt;
+    if (r < (unsigned)G3_KMIN) r = 0;
+    else if (r + G3_KMIN > (unsigned)nkt) { r = 0; ++t; }
+    return t * (unsigned)nkt + r;
+  };
+  unsigned u = (unsigned)sgpr32((int)bound(lb));
+  const unsigned u_end = (unsigned)sgpr32((int)bound(lb + 1));
+  if (u >= u_end) return;                                    // (cannot happen for U / G >= 8; kept for safety)
+
+  // ---- per-lane DMA source state (as gconv2)
+  const int q8 = lane & 7, rsub = lane >> 3;
+  const int swz0 = (lane >> 4) & 7, swz1 = (4 + (lane >> 4)) & 7;
+  const int pa0 = (q8 ^ swz0) * 16, pa1 = (q8 ^ swz1) * 16;
+  const unsigned tab_lane = lds0 + G2_TAB + (wid * 32 + rsub) * 32;
+  constexpr int BPW = CF::B_PER_WAVE;
+  gcp wb[4];
+  auto set_wb = [&](int64_t n0) {
+    const int64_t Nc = g.N;
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+      int64_t c = n0 + wid * (8 * BPW) + j * 8 + rsub;
+      c = c < Nc ? c : Nc - 1;
+      const int brow = wid * (8 * BPW) + j * 8 + rsub;
+      wb[j] = (gcp)a.W2 + c * G2_LINE + (q8 ^ ((brow >> 1) & 7)) * 16;
+    }
+  };
+
+  struct Tile { int tcol; int ktw; gcp base; };
+  auto load_idx = [&](const Tile& T, G2Idx& I) {
+    const unsigned ad = tab_lane + T.tcol * 4;
+    g2_ds_read32<0>(I.v[0], ad);
+    g2_ds_read32<256>(I.v[1], ad);
+    g2_ds_read32<512>(I.v[2], ad);
+    g2_ds_read32<768>(I.v[3], ad);
+  };
+  auto issue = [&](const Tile& T, int ob, const G2Idx& I) {
+    const gcp b0 = T.base + pa0, b1 = T.base + pa1;
+    char* const abuf = smem3 + ob + wid * (32 * G2_LINE);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds(((j & 1) ? b1 : b0) + ((uint64_t)I.v[j] << 7),
+                                       (ldsp)(abuf + j * (8 * G2_LINE)), 16, 0, 0);
+    char* const bbuf = smem3 + ob + G2_A_BYTES + wid * (8 * BPW * G2_LINE);
+    const int64_t wo = (int64_t)T.ktw * wstep;
+#pragma unroll
+    for (int j = 0; j < BPW; ++j)
+      __builtin_amdgcn_global_load_lds(wb[j] + wo, (ldsp)(bbuf + j * (8 * G2_LINE)), 16, 0, 0);
+  };
+  auto tile_of = [&](int it) {
+    Tile T;
+    if (it < nkt_g) {
+      const int chunk = it / 7, dir = it - chunk * 7;
+      T.tcol = dir; T.ktw = dir * tpd + chunk; T.base = xp_s + (int64_t)chunk * G2_LINE;
+    } else {
+      T.tcol = 7; T.ktw = it; T.base = tfp_s + (int64_t)(it - nkt_g) * G2_LINE;
+    }
+    return T;
+  };
+
+  // ---- neighbour table of a row tile, two phases:
+  //   raw_request(m0n): every wave DMAs the 32 x 7 int32 entries of its rows (896 B; the instruction moves 1 KB, the
+  //     128-B tail duplicates the next wave's head) -- addresses clamped to the end of the array;
+  //   table_convert(m0n): entry (r, d < 7) -> unsigned 128-B line offset from xlo of source row nbr_ext[m, d]
+  //     (rows >= n_src live in `aux`), entry (r, 7) -> line offset of the row's own node-type slab row from tfp.
+  auto raw_request = [&](int64_t m0n) {
+    gcp p = nbr_s + (m0n + wid * 32) * 28 + lane * 16;
+    p = p < lim_s ? p : lim_s;
+    __builtin_amdgcn_global_load_lds(p, (ldsp)(smem3 + CF::RAW + wid * CF::RAW_WAVE), 16, 0, 0);
+  };
+  // Everything these per-piece sections derive from the thread id is loop-invariant, and the compiler would compute
+  // it once in front of the piece loop and keep it (in registers it does not have: spills) across every k-step.
+  // An opaque copy of the thread id keeps the arithmetic local to its section.
+  auto opaque_tid = [&]() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+  };
+  auto table_convert = [&](int64_t m0n) {
+    const int tid = opaque_tid();
+    const int64_t left = Mrows - 1 - m0n;                               // last valid row of the tile, relative (>= 0)
+    const int rmax = left < (int64_t)(G2_BM - 1) ? (int)left : G2_BM - 1;
+    const unsigned mline = (unsigned)m0n * (unsigned)lpt;
+    G3Raw R;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int e = tid + CF::THREADS * t;
+      const int r = e >> 3, d = e & 7;
+      const int rl = r < rmax ? r : rmax;
+      const unsigned ad = lds0 + CF::RAW + (rl * 7 + (d < 7 ? d : 6)) * 4;
+      if (t == 0) g2_ds_read32<0>(R.v[0], ad);
+      else if (t == 1) g2_ds_read32<0>(R.v[1], ad);
+      else if (t == 2) g2_ds_read32<0>(R.v[2], ad);
+      else g2_ds_read32<0>(R.v[3], ad);
+    }
+    g3_wait_lgkm0(R);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int e = tid + CF::THREADS * t;
+      const int r = e >> 3, d = e & 7;
+      const int rl = r < rmax ? r : rmax;
+      const int id = (int)R.v[t];
+      const unsigned gl = id < n_src ? x_line + (unsigned)id * (unsigned)lpr
+                                     : aux_line + (unsigned)(id - n_src) * (unsigned)lpr;
+      g3_ds_write32(lds0 + G2_TAB + e * 4, d < 7 ? gl : mline + (unsigned)rl * (unsigned)lpt);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  // ---- per-lane fragment read state (as gconv2)
+  const int s7 = (l31 >> 1) & 7;
+  unsigned fa[2][2], fb[2][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      const int t = PREC == 2 ? (uu == 0 ? c : 2 + c) : 2 * c + uu;
+      const int po = ((2 * t + h) ^ s7) * 16;
+      fa[c][uu] = lds0 + (wm * 64 + l31) * G2_LINE + po;
+      fb[c][uu] = lds0 + G2_A_BYTES + (wn * (32 * G2_NI) + l31) * G2_LINE + po;
+    }
+  auto read_half = [&](int ob, int c, Half& F) {
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      g2_ds_read128<0>(F.a[uu][0], fa[c][uu] + ob);
+      g2_ds_read128<32 * G2_LINE>(F.a[uu][1], fa[c][uu] + ob);
+    }
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      g2_ds_read128<0>(F.b[uu][0], fb[c][uu] + ob);
+      if constexpr (NI == 2) g2_ds_read128<32 * G2_LINE>(F.b[uu][1], fb[c][uu] + ob);
+    }
+  };
+  auto read_one = [&](int ob, int c, Half& F, auto r_tag) {
+    constexpr int r = decltype(r_tag)::value;
+    constexpr int NA = 2 * G2_MI;
+    if constexpr (r < NA) {
+      constexpr int uu = r / G2_MI, i = r % G2_MI;
+      if constexpr (i == 0) g2_ds_read128<0>(F.a[uu][0], fa[c][uu] + ob);
+      else g2_ds_read128<32 * G2_LINE>(F.a[uu][1], fa[c][uu] + ob);
+    } else {
+      constexpr int qq = r - NA, uu = qq / G2_NI, j = qq % G2_NI;
+      if constexpr (j == 0) g2_ds_read128<0>(F.b[uu][0], fb[c][uu] + ob);
+      else g2_ds_read128<32 * G2_LINE>(F.b[uu][1], fb[c][uu] + ob);
+    }
+  };
+  f32x16 acc[G2_MI][G2_NI];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < G2_MI; ++i)
+#pragma unroll
+      for (int j = 0; j < G2_NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+
+#define G3_FENCE() __builtin_amdgcn_sched_barrier(0)
+  Half F0, F1;
+  G2Idx I;
+  auto mfma_one = [&](const Half& F, auto m_tag) {
+    constexpr int m = decltype(m_tag)::value;
+    constexpr int per = G2_MI * G2_NI, t = m / per, i = (m / G2_NI) % G2_MI, j = m % G2_NI;
+    if constexpr (PREC == 2) {
+      // [0] = hi, [1] = lo: small cross terms first, the leading term last
+      if constexpr (t == 0) acc[i][j] = g2_mfma<PREC>(F.a[1][i], F.b[0][j], acc[i][j]);
+      else if constexpr (t == 1) acc[i][j] = g2_mfma<PREC>(F.a[0][i], F.b[1][j], acc[i][j]);
+      else acc[i][j] = g2_mfma<PREC>(F.a[0][i], F.b[0][j], acc[i][j]);
+    } else {
+      acc[i][j] = g2_mfma<PREC>(F.a[t][i], F.b[t][j], acc[i][j]);
+    }
+  };
+  auto issue_one = [&](const Tile& T, int ob, const G2Idx& I, auto k_tag) {
+    constexpr int k = decltype(k_tag)::value;
+    if constexpr (k < 4) {
+      const gcp b = T.base + ((k & 1) ? pa1 : pa0);
+      __builtin_amdgcn_global_load_lds(b + ((uint64_t)I.v[k] << 7),
+                                       (ldsp)(smem3 + ob + wid * (32 * G2_LINE) + k * (8 * G2_LINE)), 16, 0, 0);
+    } else {
+      constexpr int j = k - 4;
+      __builtin_amdgcn_global_load_lds(wb[j] + (int64_t)T.ktw * wstep,
+                                       (ldsp)(smem3 + ob + G2_A_BYTES + wid * (8 * BPW * G2_LINE) + j * (8 * G2_LINE)),
+                                       16, 0, 0);
+    }
+  };
+  constexpr int NMF = (PREC == 2 ? 3 : 2) * G2_MI * G2_NI;           // MFMAs per half step
+  // MFMAs of half Fc with (a) the LDS reads of the next half set Fr and (b) optionally the DMA request of tile T
+  // spliced between them in a pinned order (gconv2's "variant 5").
+  auto mfma_spliced = [&](const Half& Fc, bool do_read, int ob_r, int c_r, Half& Fr, auto dma_tag, const Tile& T,
+                          int ob_dma) {
+    constexpr bool DMA = decltype(dma_tag)::value;
+    auto body = [&](auto m_tag) {
+      constexpr int m = decltype(m_tag)::value;
+      mfma_one(Fc, m_tag);
+      if constexpr (m < RH) {
+        if (do_read) read_one(ob_r, c_r, Fr, m_tag);
+      }
+      if constexpr (DMA) {
+        if constexpr (m == 1) {                                          // table entries: 2 younger reads so far
+          if (do_read) g2_wait_lgkm<(RH < 2 ? RH : 2)>(I);
+          else g2_wait_lgkm<0>(I);
+        }
+        if constexpr (m >= 2 && m - 2 < GLDS) issue_one(T, ob_dma, I, std::integral_constant<int, m - 2>());
+      }
+      G3_FENCE();
+    };
+    g2_static_for<NMF>(body);
+    if constexpr (RH > NMF) {
+      g2_static_for<RH>([&](auto r_tag) {
+        constexpr int r = decltype(r_tag)::value;
+        if constexpr (r >= NMF) {
+          if (do_read) read_one(ob_r, c_r, Fr, r_tag);
+        }
+      });
+    }
+    if constexpr (DMA) {
+      g2_static_for<GLDS>([&](auto k_tag) {
+        constexpr int k = decltype(k_tag)::value;
+        if constexpr (k + 2 >= NMF) issue_one(T, ob_dma, I, k_tag);
+      });
+    }
+  };
+
+  // ================================ block prologue: first piece ==============================================
+  unsigned t_cur = u / (unsigned)nkt;
+  int k0 = (int)(u - t_cur * (unsigned)nkt);
+  int tm = (int)(t_cur / (unsigned)ntn), tn = (int)t_cur - tm * ntn;
+  int64_t m0 = a.row0 + (int64_t)tm * G2_BM, n0 = (int64_t)tn * G2_BN;
+  raw_request(m0);
+  g2_wait_barrier<0>();
+  table_convert(m0);
+  set_wb(n0);
+  asm volatile("s_barrier" ::: "memory");
+  {
+    const Tile T0 = tile_of(k0);
+    load_idx(T0, I);
+    g2_wait_lgkm<0>(I);
+    issue(T0, 0, I);
+    const Tile T1 = tile_of(k0 + 1);                                    // every piece has >= G3_KMIN k tiles
+    load_idx(T1, I);
+    g2_wait_lgkm<0>(I);
+    issue(T1, G2_BUF, I);
+  }
+  int ob = 0, obn = G2_BUF, obnn = 2 * G2_BUF;                           // stage buffers of k tiles it, it+1, it+2
+  G2Epi<G2_MI, G2_NI> P;
+  const bool vec4 = g.vec4 != 0;
+  if (dbg) ts1 = g2_clock();
+
+  // ================================ piece loop ===============================================================
+  for (;;) {
+    // this piece = k tiles [k0, k1) of tile t_cur
+    const unsigned left = u_end - u;
+    const int k1 = (unsigned)(nkt - k0) <= left ? nkt : k0 + (int)left;
+    const int len = k1 - k0;
+    u += (unsigned)len;
+    const bool has_next = u < u_end;                                     // the next piece starts at k = 0 of tile t_cur + 1
+    const unsigned t_nxt = t_cur + 1;
+    const int tm_n = (int)(t_nxt / (unsigned)ntn), tn_n = (int)t_nxt - tm_n * ntn;
+    const int64_t m0_n = a.row0 + (int64_t)tm_n * G2_BM, n0_n = (int64_t)tn_n * G2_BN;
+    const bool new_rows = has_next && tm_n != tm;
+    const bool finisher = k0 == 0;
+
+    // all DMA of k tiles k0, k0+1 and every older store have landed / drained; meet, then fetch the first fragments
+    g2_wait_barrier<0>();
+    zero_acc();
+    read_half(ob, 0, F0);
+
+    // k tile it + 2 of the piece, advanced without division while it is a gather tile
+    int it = k0;
+    int gd, gc;
+    {
+      const int ti = k0 + 2;
+      gc = ti / 7; gd = ti - gc * 7;                                     // (only meaningful while ti < nkt_g)
+    }
+    auto next_tile = [&]() {
+      const int ti = it + 2;
+      const bool gat = ti < nkt_g;
+      Tile T;
+      T.tcol = gat ? gd : 7;
+      T.ktw = gat ? gd * tpd + gc : ti;
+      T.base = (gat ? xp_s : tfp_s) + (int64_t)(gat ? gc : ti - nkt_g) * G2_LINE;
+      const int wrap = gd == 6;
+      gd = wrap ? 0 : gd + 1;
+      gc += wrap;
+      return T;
+    };
+    auto epi_request = [&]() {
+      const int tid = opaque_tid();
+      const int w = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+      g2_epilogue_request<G2_WM, G2_WN, G2_MI, G2_NI>(g, (const void*)a.W2, P, m0, n0, w >> 1, w & 1, ln & 31, ln >> 5);
+    };
+    // One steady k-step.  On entry: F0 = first half of k tile `it` (reads possibly in flight), k tile it+1 requested.
+    auto step = [&](const Tile& T, auto last_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
+      if constexpr (CF::NBUF == 3) {
+        // table reads | wait F0 (4 younger) | {MFMA F0, read F1, request k tile it+2} | barrier | {MFMA F1, read F0'}
+        load_idx(T, I);
+        g2_wait_lgkm<4, PREC>(F0);
+        G3_FENCE();
+        if (LAST) {
+          epi_request();
+          G3_FENCE();
+        }
+        mfma_spliced(F0, true, ob, 1, F1, std::true_type(), T, obnn);
+        g2_wait_barrier<GLDS + (LAST ? G2_EPI_LOADS : 0), PREC>(F1);
+        G3_FENCE();
+        mfma_spliced(F1, true, obn, 0, F0, std::false_type(), T, 0);
+        const int t = ob; ob = obn; obn = obnn; obnn = t;
+      } else {
+        // wait F0 | {MFMA F0, read F1} | barrier | table reads | {MFMA F1, read F0', request k tile it+2 into the
+        // buffer k tile `it` just left}
+        g2_wait_lgkm<0, PREC>(F0);
+        G3_FENCE();
+        if (LAST) {
+          epi_request();
+          G3_FENCE();
+        }
+        mfma_spliced(F0, true, ob, 1, F1, std::false_type(), T, 0);
+        g2_wait_barrier<(LAST ? G2_EPI_LOADS : 0), PREC>(F1);
+        G3_FENCE();
+        load_idx(T, I);
+        mfma_spliced(F1, true, obn, 0, F0, std::true_type(), T, ob);
+        const int t = ob; ob = obn; obn = t;
+      }
+    };
+    // A drain k-step (the last two of a piece): nothing of THIS piece is left to request; `T` = k tile 0 / 1 of the
+    // next piece, requested in the second half through the table converted at the end of the last steady step.  The
+    // block's last piece requests them all the same (through the table and weight columns it has: valid addresses,
+    // into stage buffers nobody reads again) -- two wasted k tiles per block instead of a branch around every request.
+    // VMW: DMA instructions that may stay in flight at the barrier.
+    auto drain = [&](const Tile& T, bool do_read, auto vmw_tag) {
+      constexpr int VMW = decltype(vmw_tag)::value;
+      g2_wait_lgkm<0, PREC>(F0);
+      G3_FENCE();
+      mfma_spliced(F0, true, ob, 1, F1, std::false_type(), T, 0);
+      g2_wait_barrier<VMW, PREC>(F1);
+      G3_FENCE();
+      load_idx(T, I);
+      mfma_spliced(F1, do_read, obn, 0, F0, std::true_type(), T, CF::NBUF == 3 ? obnn : ob);
+      if (CF::NBUF == 3) { const int t = ob; ob = obn; obn = obnn; obnn = t; }
+      else { const int t = ob; ob = obn; obn = t; }
+    };
+
+    // ---- steady steps
+    bool first = true;
+    for (; it + 3 < k1; ++it) {
+      step(next_tile(), std::false_type());
+      if (first) {
+        first = false;
+        if (new_rows) raw_request(m0_n);                                // one more DMA, older than everything the next waits leave in flight
+      }
+    }
+    step(next_tile(), std::true_type());                                // it == k1 - 3: also requests the epilogue operands
+    ++it;
+    if (new_rows) {
+      // 3 stages: every wave read the old table before this step's barrier.  2 stages: the table reads sit in the
+      // second half of the step -- meet once more before overwriting it.
+      if (CF::NBUF == 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      table_convert(m0_n);
+    }
+    if (has_next) set_wb(n0_n);
+    {
+      Tile Tn = tile_of(0);
+      drain(Tn, true, std::integral_constant<int, 0>());      // k tile k1 - 1 and the epilogue operands land
+      ++it;
+      Tn = tile_of(1);
+      drain(Tn, false, std::integral_constant<int, GLDS>());
+      ++it;
+    }
+    g2_epilogue_landed(P);
+    if (dbg && dbg_piece < 6 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 4 + 2 * dbg_piece] = g2_clock();
+
+    // ---- the piece's result
+    if (finisher) {
+      if (k1 < nkt) {
+        // pieces [k1, nkt) of this tile come from the blocks after this one; their pieces were their first work
+        const unsigned u_tile_end = (t_cur + 1) * (unsigned)nkt;
+        int nc = 0;
+        for (int c = lb + 1; c < G && bound(c) < u_tile_end; ++c) ++nc;
+        if (threadIdx.x == 0) {
+          const unsigned long long tstart = g2_clock();
+          for (int c = lb + 1; c <= lb + nc; ++c) {
+            while (__hip_atomic_load(flags_s + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+              __builtin_amdgcn_s_sleep(8);
+              if (g2_clock() - tstart > (1ull << 33)) {                 // several seconds: give up, report, go on
+                __hip_atomic_store(flags_s + G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int c = lb + 1; c <= lb + nc; ++c) {
+          const char* src = reinterpret_cast<const char*>(part_s + (size_t)c * (G2_BM * G2_BN)) + opaque_tid() * 16;
+          asm volatile("" : "+v"(src));                                  // keep the address arithmetic inside this branch
+#pragma unroll
+          for (int i = 0; i < G2_MI; ++i)
+#pragma unroll
+            for (int j = 0; j < G2_NI; ++j) {
+              g2_v4f v[4];
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                v[r4] = *reinterpret_cast<const g2_v4f*>(src);
+                src += CF::THREADS * 16;
+                asm volatile("" : "+v"(src));
+              }
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                acc[i][j][4 * r4 + 0] += v[r4].x; acc[i][j][4 * r4 + 1] += v[r4].y;
+                acc[i][j][4 * r4 + 2] += v[r4].z; acc[i][j][4 * r4 + 3] += v[r4].w;
+              }
+              asm volatile("" ::: "memory");                             // four loads in flight at a time (registers)
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");    // every wave has read its slots
+        if (threadIdx.x == 0)
+          for (int c = lb + 1; c <= lb + nc; ++c)
+            __hip_atomic_store(flags_s + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      {
+        const int tid = opaque_tid();
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+        if (vec4) g2_epilogue_finish<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, P, m0, n0, w >> 1, w & 1, ln & 31, ln >> 5);
+        else epilogue_store_scalar<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, m0, n0, w >> 1, w & 1, ln & 31, ln >> 5, 0);
+      }
+    } else {
+      // a middle / tail piece: publish the raw accumulators (lane-linear float4 slabs), write-through
+      char* dst = reinterpret_cast<char*>(part_s + (size_t)lb * (G2_BM * G2_BN)) + opaque_tid() * 16;
+      asm volatile("" : "+v"(dst));                                      // (loop-invariant otherwise: hoisted and spilled)
+#pragma unroll
+      for (int i = 0; i < G2_MI; ++i)
+#pragma unroll
+        for (int j = 0; j < G2_NI; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            g2_v4f v;
+            v.x = acc[i][j][4 * r4 + 0]; v.y = acc[i][j][4 * r4 + 1];
+            v.z = acc[i][j][4 * r4 + 2]; v.w = acc[i][j][4 * r4 + 3];
+            g3_store128_sc1(dst, v);
+            dst += CF::THREADS * 16;
+            asm volatile("" : "+v"(dst));
+          }
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // EVERY storing wave drains, then meet
+      if (threadIdx.x == 0) __hip_atomic_store(flags_s + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (dbg) {
+      if (dbg_piece < 6 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 5 + 2 * dbg_piece] = g2_clock();
+      ++dbg_piece;
+    }
+    if (!has_next) break;
+    t_cur = t_nxt; k0 = 0; tm = tm_n; tn = tn_n; m0 = m0_n; n0 = n0_n;
+  }
+#undef G3_FENCE
+  // the last piece's drain steps requested two k tiles nobody reads: they must have landed before the LDS is released
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (dbg) {
+    // [blocks][16] shader-clock stamps: entry, first piece ready, pieces, exit; then per piece (<= 6) k-loop done /
+    // result written
+    const unsigned long long ts4 = g2_clock();
+    if (threadIdx.x == 0) {
+      unsigned long long* o = a.dbg + (size_t)blockIdx.x * 16;
+      o[0] = ts0; o[1] = ts1; o[2] = (unsigned long long)dbg_piece; o[3] = ts4;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int PREC, int WM, int NI>
+static int g3_launch(const Gemm3Args& A, hipStream_t st) {
+  static bool attr_set[OFX_MAX_DEVICES] = {};
+  if (!ofx_raise_lds_limit(reinterpret_cast<const void*>(&gconv3_kernel<PREC, WM, NI>), G3Cfg<WM, NI>::LDS, attr_set))
+    return OFX_ELAUNCH;
+  gconv3_kernel<PREC, WM, NI><<<A.G, G3Cfg<WM, NI>::THREADS, G3Cfg<WM, NI>::LDS, st>>>(A);
+  return OFX_OK;
+}
+
+static int g3_cus() {                  // compute units of the current device (cached per device)
+  static int cus[OFX_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= OFX_MAX_DEVICES) return 0;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
+// Bytes of workspace the persistent launch needs behind the statistics partials (0: the shape is not eligible).
+// Launch plan: wm (2 / 4), ni (1 / 2) -> blocks G, units per block.
+struct G3Plan { int G; unsigned q, rem, U; size_t part_bytes; };
+static bool g3_plan(int64_t M, int cout, int nkt, int wm, int ni, G3Plan& p) {
+  const int cus = g3_cus();
+  if (cus < 8 || nkt < 7) return false;
+  const int64_t tiles = ofx_cdiv(M, wm * 64) * ofx_cdiv(cout, 64 * ni);
+  const int64_t U = tiles * nkt;
+  if (U >= (1ll << 31) || U < 64) return false;
+  int64_t slots = (int64_t)cus * (wm == 4 ? 1 : 2);
+  int64_t G = slots < U / 8 ? slots : U / 8;
+  G &= ~7ll;
+  if (G < 8) return false;
+  p.G = (int)G; p.U = (unsigned)U; p.q = (unsigned)(U / G); p.rem = (unsigned)(U % G);
+  p.part_bytes = (size_t)G * (size_t)(wm * 64) * (size_t)(64 * ni) * sizeof(float);
+  return true;
+}
+
+// Called by ofx_graphconv_fwd_planes (ofx_gemm2.hip) once it has filled the common arguments.
+// Returns OFX_OK (launched), a failure status, or 1 when the shape / workspace does not qualify (caller falls back
+// to the one-tile-per-block kernel).
+int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, size_t ws_tail_bytes, void* sync,
+                      size_t sync_bytes, hipStream_t st) {
+  G3Plan p;
+  GemmArgs& g = a.e;
+  if (!sync || ((uintptr_t)sync & 3) || !ws_tail || ((uintptr_t)ws_tail & 15)) return 1;
+  if (!g3_plan(g.M, (int)g.N, a.nkt, wm, ni, p)) return 1;
+  if (p.part_bytes > ws_tail_bytes || (size_t)(p.G + 1) * sizeof(unsigned) > sync_bytes) return 1;
+  if ((a.ldx >> 7) >= (1 << 20) || (a.ldt >> 7) >= (1 << 20) || a.n_src >= (1ll << 31)) return 1;
+  Gemm3Args A = {};
+  a.row0 = 0;
+  g.ntm = (int)ofx_cdiv(g.M, wm * 64);
+  A.b = a;
+  A.G = p.G; A.q = p.q; A.rem = p.rem; A.U = p.U;
+  A.part = (float*)ws_tail; A.flags = (unsigned*)sync;
+  // last 16-B chunk that still starts inside the array (a chunk may run up to 12 B past the last entry: the caller
+  // guarantees 16 B of readable slack behind nbr_ext, include/ofx.h)
+  A.nbr_lim = (const char*)a.nbr_ext + ((((size_t)g.M * 28 - 4) >> 4) << 4);
+  if (((uintptr_t)a.nbr_ext & 15)) return 1;
+#define G3_GO(P_)                                                                                         \
+  (ni == 1 ? (wm == 4 ? g3_launch<P_, 4, 1>(A, st) : g3_launch<P_, 2, 1>(A, st))                          \
+           : (wm == 4 ? g3_launch<P_, 4, 2>(A, st) : g3_launch<P_, 2, 2>(A, st)))
+  return mode == 2 ? G3_GO(2) : G3_GO(1);
+#undef G3_GO
+}

@@ -1,0 +1,331 @@
+// Device helpers shared by the planes GraphConv kernels (ofx_gemm2.hip: one tile per block; ofx_gemm3.hip:
+// persistent stream-K blocks): tile geometry, MFMA fragment types, the hand-counted inline-asm LDS reads / waits
+// and the two-phase epilogue.
+#pragma once
+#include <type_traits>
+#include <utility>
+
+#include "ofx_gemm_common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const char __attribute__((address_space(1)))* gcp;
+typedef __attribute__((address_space(3))) void* ldsp;
+
+// Two block geometries (template parameter WM = wave rows):
+//   WM = 4: 256 x 128 tile, 8 waves, 3 stage buffers (DMA two k-steps ahead), 152 KB LDS -> ONE block per CU;
+//   WM = 2: 128 x 128 tile, 4 waves, 2 stage buffers (DMA one k-step ahead),  68 KB LDS -> TWO blocks per CU: the
+//           prologue (table + first DMA), the epilogue (residual reads, stores) and every barrier wait of one
+//           block overlap the other block's MFMAs, at the price of 1/3 more operand bytes per MFMA (the weight tile
+//           is shared by 128 rows instead of 256).
+// Output width: NI = 2 -> 128-column tiles (wave tile 64 x 64); NI = 1 -> 64-column tiles (wave tile 64 x 32) for the
+// cout <= 64 layers (the depth-8 layers of the 3-stage feature net), which would waste half their MFMAs on clamped
+// columns of a 128-wide tile.
+constexpr int G2_WN = 2, G2_MI = 2;
+constexpr int G2_LINE = 128;                          // bytes per row per k-step (both precisions)
+template <int WM, int NI = 2> struct G2Cfg {
+  static constexpr int BN = G2_WN * NI * 32;
+  static constexpr int B_BYTES = BN * G2_LINE;
+  static constexpr int BM = WM * G2_MI * 32;
+  static constexpr int WAVES = WM * G2_WN;
+  static constexpr int THREADS = WAVES * 64;
+  static constexpr int NBUF = WM == 4 ? 3 : 2;
+  static constexpr int A_BYTES = BM * G2_LINE;
+  static constexpr int BUF = A_BYTES + B_BYTES;       // one stage
+  static constexpr int TAB = NBUF * BUF;              // neighbour-table slice [BM][8] uint32
+  static constexpr int PFS = TAB + BM * 8 * 4;        // 256-B landing pad of the table prefetch (never read)
+  static constexpr int LDS = PFS + 256;               // 155 904 B (WM 4) / 69 888 B (WM 2)
+  static constexpr int B_PER_WAVE = (BN / 8) / WAVES;                 // weight-tile DMA instructions per wave: 1, 2 or 4
+  static constexpr int READS = 2 * (G2_MI + NI);                      // LDS reads of one half-step fragment set
+  static constexpr int EPI_LOADS = G2_MI * NI * 4 + NI + G2_MI * 4;   // epilogue operand requests per lane (26 / 17)
+  static constexpr int GLDS = 4 + B_PER_WAVE;                         // DMA instructions per wave per k-step: 6 / 8
+};
+
+struct Gemm2Args {
+  const char* xp; int64_t ldx;            // activation planes; row pitch in BYTES
+  const char* aux;                        // rows n_src.. of the id space: [0] zeros, [1 + v] multi-neighbour means
+  int64_t n_src;
+  const int32_t* nbr_ext;                 // [M, 7]
+  const char* tfp; int64_t ldt;           // node-type slab planes (row pitch bytes) or the activation planes again
+  const char* W2;                         // [nkt][N][128 B]
+  int tpd, nkt_g, nkt;                    // k tiles per direction, gather tiles (7 * tpd), all tiles
+  unsigned long long* dbg;                // optional [blocks][8] shader-clock stamps (ofx_set_gconv2_debug)
+  int stagger;                            // shader clocks the second block of each CU waits before its first tile (WM 2)
+  int prefetch;                           // number of co-resident blocks S (256 x blocks per CU); block b pulls the
+                                          // neighbour-table slice of block b + S (same XCD, one round later) into L2
+  int prefetch_on;
+  int64_t row0;                           // first output row of this launch (bulk + remainder launches split the rows)
+  GemmArgs e;                             // M, N, epilogue operands, tile grid
+};
+
+__device__ __forceinline__ unsigned long long g2_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+  return t;
+}
+
+// compile-time unrolled loop: f(std::integral_constant<int, 0>()), ..., f(std::integral_constant<int, N - 1>())
+template <typename F, int... Is>
+__device__ __forceinline__ void g2_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>()), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void g2_static_for(F&& f) {
+  g2_static_for_impl(f, std::make_integer_sequence<int, N>());
+}
+
+template <int PREC> struct G2Frag;
+template <> struct G2Frag<2> { typedef bf16x8_t T; };
+template <> struct G2Frag<1> { typedef f16x8_t T; };
+
+template <int PREC>
+__device__ __forceinline__ f32x16 g2_mfma(typename G2Frag<PREC>::T a, typename G2Frag<PREC>::T b, f32x16 c);
+template <>
+__device__ __forceinline__ f32x16 g2_mfma<2>(bf16x8_t a, bf16x8_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16 g2_mfma<1>(f16x8_t a, f16x8_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// ---- LDS reads of the k-loop are INLINE ASM with hand-counted waits.  With a global_load_lds anywhere in a loop
+// hipcc's waitcnt pass stops counting LDS reads and puts `s_waitcnt lgkmcnt(0)` in front of every consumer (checked
+// on a 40-line reproducer), which would serialise the fragment reads of the next half step with the MFMAs of the
+// current one.  Every wait names the registers it guards as "+v" operands, so no consumer can be scheduled above it.
+template <int OFF, typename T>
+__device__ __forceinline__ void g2_ds_read128(T& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void g2_ds_read32(uint32_t& d, unsigned addr) {
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+// half-step fragment set: two piece classes of every A / B fragment of the 64 x 64 wave tile
+template <int PREC, int NI> struct G2Half { typename G2Frag<PREC>::T a[2][G2_MI], b[2][NI]; };
+// wait until at most N younger LDS reads of this wave are outstanding; guards fragment set F
+template <int N, int PREC>
+__device__ __forceinline__ void g2_wait_lgkm(G2Half<PREC, 2>& F) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[0][1]),
+                 "+v"(F.b[1][0]), "+v"(F.b[1][1])
+               : "n"(N));
+}
+template <int N, int PREC>
+__device__ __forceinline__ void g2_wait_lgkm(G2Half<PREC, 1>& F) {
+  asm volatile("s_waitcnt lgkmcnt(%6)"
+               : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[1][0])
+               : "n"(N));
+}
+// wait for all but the newest VM DMA instructions of this wave and for ALL its LDS reads (guarding F), then meet
+// the block.  The memory clobber keeps DMA issues and LDS traffic on their side of the barrier.
+template <int VM, int PREC, bool BAR = true>
+__device__ __forceinline__ void g2_wait_barrier(G2Half<PREC, 2>& F) {
+  if (!BAR) {                  // ablation only: the waits without the block-wide rendezvous
+    asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)"
+                 : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[0][1]),
+                   "+v"(F.b[1][0]), "+v"(F.b[1][1])
+                 : "n"(VM)
+                 : "memory");
+    return;
+  }
+  asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)\n\ts_barrier"
+               : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[0][1]),
+                 "+v"(F.b[1][0]), "+v"(F.b[1][1])
+               : "n"(VM)
+               : "memory");
+}
+template <int VM, int PREC, bool BAR = true>
+__device__ __forceinline__ void g2_wait_barrier(G2Half<PREC, 1>& F) {
+  asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)\n\ts_barrier"
+               : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[1][0])
+               : "n"(VM)
+               : "memory");
+}
+template <int PREC>
+__device__ __forceinline__ void g2_touch(G2Half<PREC, 2>& F) {
+  asm volatile("" : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[0][1]),
+               "+v"(F.b[1][0]), "+v"(F.b[1][1]));
+}
+template <int PREC>
+__device__ __forceinline__ void g2_touch(G2Half<PREC, 1>& F) {
+  asm volatile("" : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), "+v"(F.b[1][0]));
+}
+struct G2Idx { uint32_t v[4]; };
+template <int N>
+__device__ __forceinline__ void g2_wait_lgkm(G2Idx& I) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(I.v[0]), "+v"(I.v[1]), "+v"(I.v[2]), "+v"(I.v[3]) : "n"(N));
+}
+template <int VM>
+__device__ __forceinline__ void g2_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
+}
+
+// ---- two-phase epilogue.  With ONE block per CU nothing else hides the latency of the epilogue's own loads: the
+// shared epilogue (ofx_gemm_common.h) loads a residual piece, waits for it, stores, 16 times over -- measured at
+// 51 k shader clocks per block against 57 k for the whole 30-step k-loop (tools/gconv2_timeline.py).  Here every
+// operand the epilogue needs (residual rows, bias, time-embedding rows, batch ids) is REQUESTED before the last
+// two k-steps and consumed after them.  Same lane -> element mapping as epilogue_store_v4: lane (k = l31 >> 2,
+// q = l31 & 3, h) owns rows q + 4h + 8G + 32i (G < 4, i < MI) of its wave's 32 MI rows, columns 4k..4k+3 of every
+// 32-column group j.
+typedef float g2_v4f __attribute__((ext_vector_type(4)));
+template <int MI, int NI>
+struct G2Epi {
+  g2_v4f res[MI][NI][4];
+  g2_v4f bias[NI];
+  int bids[MI][4];
+};
+
+// The requests are inline asm: their NUMBER enters a counted s_waitcnt vmcnt(N) of the k-loop (the DMA of the next
+// tile must be waited for without waiting for these), so the compiler must neither merge, drop nor reorder them.
+// Absent operands (no residual / bias / batch ids) read a dummy line of the packed weights instead.
+__device__ __forceinline__ void g2_req128(g2_v4f& d, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p));
+}
+__device__ __forceinline__ void g2_req32(int& d, const void* p) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p));
+}
+
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void g2_epilogue_request(const GemmArgs& g, const void* dummy, G2Epi<MI, NI>& P, int64_t m0,
+                                                    int64_t n0, int wm, int wn, int l31, int h) {
+  const int q = l31 & 3, k = l31 >> 2;
+  const int64_t mw = m0 + wm * MI * 32;
+  const int64_t mlast = g.M - 1;
+  const bool need_bid = g.emb || g.stats;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+      int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
+      m = m < mlast ? m : mlast;
+      g2_req32(P.bids[i][G], need_bid ? (const void*)(g.bid + m) : dummy);
+    }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
+    n = n < g.N ? n : g.N - 4;                               // clamped: out-of-range columns are never stored
+    g2_req128(P.bias[j], g.bias ? (const void*)(g.bias + n) : dummy);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {
+        int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
+        m = m < mlast ? m : mlast;
+        g2_req128(P.res[i][j][G], g.res ? (const void*)(g.res + m * g.ldr + n) : dummy);
+      }
+  }
+}
+// after the vmcnt(0) of the last k-steps: ties every requested register to this point of the instruction stream
+__device__ __forceinline__ void g2_epilogue_landed(G2Epi<2, 2>& P) {
+  asm volatile("" : "+v"(P.res[0][0][0]), "+v"(P.res[0][0][1]), "+v"(P.res[0][0][2]), "+v"(P.res[0][0][3]),
+                    "+v"(P.res[0][1][0]), "+v"(P.res[0][1][1]), "+v"(P.res[0][1][2]), "+v"(P.res[0][1][3]),
+                    "+v"(P.res[1][0][0]), "+v"(P.res[1][0][1]), "+v"(P.res[1][0][2]), "+v"(P.res[1][0][3]),
+                    "+v"(P.res[1][1][0]), "+v"(P.res[1][1][1]), "+v"(P.res[1][1][2]), "+v"(P.res[1][1][3]),
+                    "+v"(P.bias[0]), "+v"(P.bias[1]));
+  asm volatile("" : "+v"(P.bids[0][0]), "+v"(P.bids[0][1]), "+v"(P.bids[0][2]), "+v"(P.bids[0][3]),
+                    "+v"(P.bids[1][0]), "+v"(P.bids[1][1]), "+v"(P.bids[1][2]), "+v"(P.bids[1][3]));
+}
+__device__ __forceinline__ void g2_epilogue_landed(G2Epi<2, 1>& P) {
+  asm volatile("" : "+v"(P.res[0][0][0]), "+v"(P.res[0][0][1]), "+v"(P.res[0][0][2]), "+v"(P.res[0][0][3]),
+                    "+v"(P.res[1][0][0]), "+v"(P.res[1][0][1]), "+v"(P.res[1][0][2]), "+v"(P.res[1][0][3]),
+                    "+v"(P.bias[0]));
+  asm volatile("" : "+v"(P.bids[0][0]), "+v"(P.bids[0][1]), "+v"(P.bids[0][2]), "+v"(P.bids[0][3]),
+                    "+v"(P.bids[1][0]), "+v"(P.bids[1][1]), "+v"(P.bids[1][2]), "+v"(P.bids[1][3]));
+}
+
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&acc)[MI][NI], G2Epi<MI, NI>& P, int64_t m0,
+                                                   int64_t n0, int wm, int wn, int l31, int h) {
+  const int q = l31 & 3, k = l31 >> 2;
+  const bool q0 = q & 1, q1 = q & 2;
+  const int64_t mw = m0 + wm * MI * 32;
+  const int64_t tile_m = m0 / (WM * MI * 32);
+  bool uni = true;
+  int b0 = 0;
+  if (g.emb || g.stats) {
+    // batch id of the wave's first row = lane 0's first row (reading it here, not in the request phase, keeps a
+    // scalarised load + wait out of the k-loop's tail)
+    b0 = __builtin_amdgcn_readfirstlane(P.bids[0][0]);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int G = 0; G < 4; ++G) uni = uni && (P.bids[i][G] == b0);
+    uni = __all(uni);
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
+    const bool ncol = n < g.N;
+    const int64_t nc = ncol ? n : g.N - 4;
+    float4 eu = f4zero();
+    if (g.emb && uni) eu = *reinterpret_cast<const float4*>(g.emb + (int64_t)b0 * g.lde + nc);
+    const float4 bv = g.bias ? make_float4(P.bias[j].x, P.bias[j].y, P.bias[j].z, P.bias[j].w) : f4zero();
+    float4 ssum = f4zero(), ssq = f4zero();
+    int sb = -1;
+    auto flush = [&](int b) {
+      double* o = g.stats + ((int64_t)b * g.stats_ld + n) * 2;
+      unsafeAtomicAdd(o + 0, (double)ssum.x); unsafeAtomicAdd(o + 1, (double)ssq.x);
+      unsafeAtomicAdd(o + 2, (double)ssum.y); unsafeAtomicAdd(o + 3, (double)ssq.y);
+      unsafeAtomicAdd(o + 4, (double)ssum.z); unsafeAtomicAdd(o + 5, (double)ssq.z);
+      unsafeAtomicAdd(o + 6, (double)ssum.w); unsafeAtomicAdd(o + 7, (double)ssq.w);
+    };
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float4 t[4];
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {                         // every lane takes part in the transposes
+        float v0 = acc[i][j][4 * G], v1 = acc[i][j][4 * G + 1], v2 = acc[i][j][4 * G + 2], v3 = acc[i][j][4 * G + 3];
+        quad_transpose(v0, v1, v2, v3, q0, q1);
+        t[G] = make_float4(v0 + bv.x, v1 + bv.y, v2 + bv.z, v3 + bv.w);
+      }
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {
+        const int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
+        if (m >= g.M || !ncol) continue;
+        float4 v = t[G];
+        if (g.emb) {
+          if (uni) f4add(v, eu);
+          else f4add(v, *reinterpret_cast<const float4*>(g.emb + (int64_t)P.bids[i][G] * g.lde + n));
+        }
+        if (g.res) f4add(v, make_float4(P.res[i][j][G].x, P.res[i][j][G].y, P.res[i][j][G].z, P.res[i][j][G].w));
+        if (g.stats) {
+          const int b = P.bids[i][G];
+          if (!uni && b != sb) {
+            if (sb >= 0) flush(sb);
+            ssum = f4zero(); ssq = f4zero();
+          }
+          sb = b;
+          f4add(ssum, v);
+          ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
+        }
+        *reinterpret_cast<float4*>(g.out + m * g.ldc + n) = v;
+      }
+    }
+    if (g.stats) {
+      if (uni) {
+#define OFX_RED(f) f += dpp_xor1(f); f += dpp_xor2(f); f += __shfl_xor(f, 32);
+        OFX_RED(ssum.x) OFX_RED(ssum.y) OFX_RED(ssum.z) OFX_RED(ssum.w)
+        OFX_RED(ssq.x) OFX_RED(ssq.y) OFX_RED(ssq.z) OFX_RED(ssq.w)
+#undef OFX_RED
+        if (q == 0 && h == 0 && ncol && mw < g.M) {
+          if (g.stats_part) {
+            float* o = g.stats_part + ((tile_m * WM + wm) * g.N + n) * 2;
+            *reinterpret_cast<float4*>(o) = make_float4(ssum.x, ssq.x, ssum.y, ssq.y);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(ssum.z, ssq.z, ssum.w, ssq.w);
+          } else {
+            flush(b0);
+          }
+        }
+      } else {
+        if (sb >= 0 && ncol) flush(sb);
+        if (g.stats_part && q == 0 && h == 0 && ncol && mw < g.M) {      // mixed wave: its slot must read as zero
+          float* o = g.stats_part + ((tile_m * WM + wm) * g.N + n) * 2;
+          *reinterpret_cast<float4*>(o) = f4zero();
+          *reinterpret_cast<float4*>(o + 4) = f4zero();
+        }
+      }
+    }
+  }
+}

@@ -163,7 +163,8 @@ class DualOctree:
         nbr = torch.empty(N * 7, dtype=torch.int32, device=dev)
         call('ofx_graph_primary', ptr(seg_ptr), ptr(col), N, ptr(nbr), stream())
         self._nbr[d] = nbr
-        nbr_ext = torch.empty(N * 7, dtype=torch.int32, device=dev)
+        # + 4 entries: the persistent GraphConv fetches the table in 16-B chunks and may read 12 B past the end (ofx.h)
+        nbr_ext = torch.zeros(N * 7 + 4, dtype=torch.int32, device=dev)[:N * 7]
         multi_seg = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
         call('ofx_graph_primary_ext', ptr(seg_ptr), ptr(col), N, ptr(rank), ptr(nbr_ext), ptr(multi_seg), stream())
         self._ext[d] = (nbr_ext, multi_seg, V)

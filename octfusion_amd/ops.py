@@ -192,10 +192,11 @@ def graphconv_planes(xp, mode, seg_ptr, col, ext, pw, cin, nt, tf_planes=None, b
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
     ws = workspace(xp.device)
+    sync = sync_words(xp.device)
     call('ofx_graphconv_fwd_planes', ptr(xp), ldx, cin, N, ptr(seg_ptr), ptr(col), ptr(nbr_ext), ptr(multi_seg),
-         n_multi, ptr(aux), ptr(tf_planes), ldt, nt, ptr(pw.t), pw.N, ptr(bias), ptr(emb), lde,
-         ptr(batch_id) if (emb is not None or stats is not None) else None, ptr(res), ldr, ptr(out), ldc,
-         ptr(stats), pw.N, ptr(ws), ws.numel(), mode, aux_ready, stream())
+         n_multi, ptr(aux), aux.numel() * aux.element_size(), ptr(tf_planes), ldt, nt, ptr(pw.t), pw.N, ptr(bias),
+         ptr(emb), lde, ptr(batch_id) if (emb is not None or stats is not None) else None, ptr(res), ldr, ptr(out),
+         ldc, ptr(stats), pw.N, ptr(ws), ws.numel(), ptr(sync), sync.numel() * 4, mode, aux_ready, stream())
     if prof is not None:
         e1.record()
         E = col.numel()
@@ -221,7 +222,27 @@ def side_stream(device):
     return s
 
 
-def workspace(device, nbytes=64 << 20):
+_SYNC = {}
+SYNC_WORDS = 4096
+
+
+def sync_words(device):
+    """Per-device flag words of the persistent stream-K GraphConv (include/ofx.h): zero at allocation, every launch
+    leaves them zero; the word behind the last block's flag is a sticky error flag (sync_error())."""
+    key = (device.type, device.index)
+    t = _SYNC.get(key)
+    if t is None:
+        t = _SYNC[key] = torch.zeros(SYNC_WORDS, dtype=torch.int32, device=device)
+    return t
+
+
+def sync_error(device):
+    """True if a bounded wait of a persistent launch on `device` ever gave up (host sync; tests / smoke only)."""
+    t = _SYNC.get((device.type, device.index))
+    return bool(t is not None and int(t.abs().sum().item()) != 0)
+
+
+def workspace(device, nbytes=96 << 20):
     """Per-device split-K scratch (partial tiles); reused by every launch -- launches are ordered on one stream.  Only
     with the side-stream experiment on (two streams run concurrently) it is kept per stream."""
     sid = torch.cuda.current_stream(device).cuda_stream if (SIDE_STREAM and device.type == 'cuda') else 0

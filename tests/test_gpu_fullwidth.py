@@ -241,8 +241,9 @@ def test_per_layer_sweep():
     report(dict(test='layer_sweep_worst', shapes=len(shapes), **{'%s_%s' % k: v for k, v in worst.items()}))
 
 
+@pytest.mark.parametrize('persistent', [1, 0])
 @pytest.mark.parametrize('prec', ['bf16x3', 'fp16'])
-def test_planes_kernel_edge_cases(prec):
+def test_planes_kernel_edge_cases(prec, persistent):
     """The LDS-DMA planes GraphConv off the beaten path: ragged batch of 5 with an element that has nothing below the
     full layer (tile / wave boundaries fall inside batch elements: mixed-batch statistics), output widths that are
     not multiples of the 128 / 64-column tiles (200, 72, 64, 132) incl. the clamped-column path, every block geometry
@@ -263,6 +264,7 @@ def test_planes_kernel_edge_cases(prec):
     saved = (ops.get_precision(), ops.PLANES_MIN_TILES)
     ops.set_precision(prec)
     ops.PLANES_MIN_TILES = 1
+    _lib.call('ofx_set_gconv_persistent', persistent)       # stream-K blocks / one tile per block (tests/test_gpu_persistent.py)
     try:
         for d, cin, cout, nt, bias in [(5, 64, 200, 4, True), (5, 128, 72, 4, False), (4, 192, 64, 3, True),
                                        (5, 64, 132, 0, False), (3, 64, 128, 2, True)]:
@@ -308,7 +310,11 @@ def test_planes_kernel_edge_cases(prec):
                 y2 = conv(ops.planes_split(hf, mode), doc, d, emb=emb.to(dev()), res=res.to(dev()))
                 assert errors(y2, ref)['rel_to_max'] < tol
                 outs.append(y)
-            assert torch.equal(outs[0], outs[1]), 'geometries disagree bit-wise'
+            if persistent:      # tiles cut by a share boundary are summed in two groups: same arithmetic, other rounding
+                assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * float(outs[0].abs().max())
+                assert not ops.sync_error(dev())
+            else:
+                assert torch.equal(outs[0], outs[1]), 'geometries disagree bit-wise'
             report(dict(test='planes_edge', precision=prec, depth=d, N=N, cin=cin, cout=cout, nt=nt, **errors(outs[0], ref)))
         # a graph level with a handful of rows (depth-3 full layer of ONE tiny tree: 512 rows < one 256-row tile x 2)
         tiny = C.random_split_small(1, 2, 7, p=0.5)
@@ -322,5 +328,6 @@ def test_planes_kernel_edge_cases(prec):
         assert errors(y, ref)['rel_to_max'] < tol
     finally:
         _lib.call('ofx_set_gconv2_tile', 0)
+        _lib.call('ofx_set_gconv_persistent', 1)
         ops.set_precision(saved[0])
         ops.PLANES_MIN_TILES = saved[1]

@@ -24,7 +24,10 @@
 // {steady..., last steady (requests the epilogue operands), drain A, drain B}.
 #include "ofx_planes.h"
 
-constexpr int G3_KMIN = 4;
+#ifndef G3_NSP
+#define G3_NSP 5               // k-steps the epilogue operand requests of a piece are spread over (A/B: -DG3_NSP=3)
+#endif
+constexpr int G3_KMIN = G3_NSP + 3;     // shortest piece: one plain step + the request steps + two drain steps
 
 template <int WM, int NI> struct G3Cfg : G2Cfg<WM, NI> {
   typedef G2Cfg<WM, NI> B;
@@ -42,6 +45,9 @@ struct Gemm3Args {
   float* part;                 // [G][BM * BN] raw accumulator pieces
   unsigned* flags;             // [G + 1], zero on entry and on exit; flags[G] != 0: a spin gave up
   const char* nbr_lim;         // last 16-B aligned address inside nbr_ext that may be read
+  int early;                   // every share spans >= one tile (a tile is cut at most once, and its second piece is
+                               // published before the finisher STARTS its own): the finisher starts from that piece
+                               // instead of adding it at the end
 };
 
 __device__ __forceinline__ void g3_ds_write32(unsigned addr, unsigned v) {
@@ -117,7 +123,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
   };
   unsigned u = (unsigned)sgpr32((int)bound(lb));
   const unsigned u_end = (unsigned)sgpr32((int)bound(lb + 1));
-  if (u >= u_end) return;                                    // (cannot happen for U / G >= 8; kept for safety)
+  if (u >= u_end) return;                                    // (cannot happen for U / G >= 2 * G3_KMIN; kept for safety)
 
   // ---- per-lane DMA source state (as gconv2)
   const int q8 = lane & 7, rsub = lane >> 3;
@@ -126,14 +132,17 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
   const unsigned tab_lane = lds0 + G2_TAB + (wid * 32 + rsub) * 32;
   constexpr int BPW = CF::B_PER_WAVE;
   gcp wb[4];
-  auto set_wb = [&](int64_t n0) {
+  auto set_wb = [&](int64_t n0) {                 // (once per piece: lane arithmetic on an opaque id, see opaque_tid)
     const int64_t Nc = g.N;
+    int ln = threadIdx.x & 63;
+    asm volatile("" : "+v"(ln));
+    const int q8_ = ln & 7, rsub_ = ln >> 3;
 #pragma unroll
     for (int j = 0; j < BPW; ++j) {
-      int64_t c = n0 + wid * (8 * BPW) + j * 8 + rsub;
+      int64_t c = n0 + wid * (8 * BPW) + j * 8 + rsub_;
       c = c < Nc ? c : Nc - 1;
-      const int brow = wid * (8 * BPW) + j * 8 + rsub;
-      wb[j] = (gcp)a.W2 + c * G2_LINE + (q8 ^ ((brow >> 1) & 7)) * 16;
+      const int brow = wid * (8 * BPW) + j * 8 + rsub_;
+      wb[j] = (gcp)a.W2 + c * G2_LINE + (q8_ ^ ((brow >> 1) & 7)) * 16;
     }
   };
 
@@ -169,16 +178,6 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
     return T;
   };
 
-  // ---- neighbour table of a row tile, two phases:
-  //   raw_request(m0n): every wave DMAs the 32 x 7 int32 entries of its rows (896 B; the instruction moves 1 KB, the
-  //     128-B tail duplicates the next wave's head) -- addresses clamped to the end of the array;
-  //   table_convert(m0n): entry (r, d < 7) -> unsigned 128-B line offset from xlo of source row nbr_ext[m, d]
-  //     (rows >= n_src live in `aux`), entry (r, 7) -> line offset of the row's own node-type slab row from tfp.
-  auto raw_request = [&](int64_t m0n) {
-    gcp p = nbr_s + (m0n + wid * 32) * 28 + lane * 16;
-    p = p < lim_s ? p : lim_s;
-    __builtin_amdgcn_global_load_lds(p, (ldsp)(smem3 + CF::RAW + wid * CF::RAW_WAVE), 16, 0, 0);
-  };
   // Everything these per-piece sections derive from the thread id is loop-invariant, and the compiler would compute
   // it once in front of the piece loop and keep it (in registers it does not have: spills) across every k-step.
   // An opaque copy of the thread id keeps the arithmetic local to its section.
@@ -186,6 +185,16 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
     return t;
+  };
+  // ---- neighbour table of a row tile, two phases:
+  //   raw_request(m0n): every wave DMAs the 32 x 7 int32 entries of its rows (896 B; the instruction moves 1 KB, the
+  //     128-B tail duplicates the next wave's head) -- addresses clamped to the end of the array;
+  //   table_convert(m0n): entry (r, d < 7) -> unsigned 128-B line offset from xlo of source row nbr_ext[m, d]
+  //     (rows >= n_src live in `aux`), entry (r, 7) -> line offset of the row's own node-type slab row from tfp.
+  auto raw_request = [&](int64_t m0n) {
+    gcp p = nbr_s + (m0n + wid * 32) * 28 + (opaque_tid() & 63) * 16;
+    p = p < lim_s ? p : lim_s;
+    __builtin_amdgcn_global_load_lds(p, (ldsp)(smem3 + CF::RAW + wid * CF::RAW_WAVE), 16, 0, 0);
   };
   auto table_convert = [&](int64_t m0n) {
     const int tid = opaque_tid();
@@ -353,8 +362,27 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
   }
   int ob = 0, obn = G2_BUF, obnn = 2 * G2_BUF;                           // stage buffers of k tiles it, it+1, it+2
   G2Epi<G2_MI, G2_NI> P;
-  const bool vec4 = g.vec4 != 0;
   if (dbg) ts1 = g2_clock();
+
+  bool flag_pending = false;
+  const bool early = A.early != 0;
+  // one lane polls the flags of the next `n` blocks (relaxed), ONE agent-scope acquire, everybody meets
+  auto wait_flags = [&](int n) {
+    if (threadIdx.x == 0) {
+      const unsigned long long tstart = g2_clock();
+      for (int c = lb + 1; c <= lb + n; ++c) {
+        while (__hip_atomic_load(flags_s + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(8);
+          if (g2_clock() - tstart > (1ull << 33)) {                     // several seconds: give up, report, go on
+            __hip_atomic_store(flags_s + G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
 
   // ================================ piece loop ===============================================================
   for (;;) {
@@ -370,9 +398,44 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
     const bool new_rows = has_next && tm_n != tm;
     const bool finisher = k0 == 0;
 
+    const bool cut_head = finisher && k1 < nkt;                          // k tiles [k1, nkt) come from the next block(s)
+
+    // batch element of this wave's first output row, for the time-embedding line of the epilogue requests (asked for
+    // here so that its latency is this wait's, not the last k-steps')
+    int b0v = 0;
+    const bool emb_line = g.emb && !g.bias;
+    if (emb_line) {
+      const int64_t mw = m0 + (wid >> 1) * (G2_MI * 32);
+      g2_req32(b0v, g.bid + (mw < Mrows - 1 ? mw : Mrows - 1));
+    }
     // all DMA of k tiles k0, k0+1 and every older store have landed / drained; meet, then fetch the first fragments
     g2_wait_barrier<0>();
-    zero_acc();
+    asm volatile("" : "+v"(b0v));
+    const int b0w = emb_line ? __builtin_amdgcn_readfirstlane(b0v) : -1;
+    if (flag_pending) {                                                  // the piece published before this one: every wave has drained
+      if (threadIdx.x == 0) __hip_atomic_store(flags_s + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag_pending = false;
+    }
+    if (cut_head && early) {
+      // start from the other piece of the tile (published long ago: it was its block's first work) instead of zero:
+      // its 16 loads per lane go straight into the accumulators and fly together
+      wait_flags(1);
+      const char* src = reinterpret_cast<const char*>(part_s + (size_t)(lb + 1) * (G2_BM * G2_BN)) + opaque_tid() * 16;
+#pragma unroll
+      for (int i = 0; i < G2_MI; ++i)
+#pragma unroll
+        for (int j = 0; j < G2_NI; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const g2_v4f v = *reinterpret_cast<const g2_v4f*>(src + ((i * G2_NI + j) * 4 + r4) * (CF::THREADS * 16));
+            acc[i][j][4 * r4 + 0] = v.x; acc[i][j][4 * r4 + 1] = v.y;
+            acc[i][j][4 * r4 + 2] = v.z; acc[i][j][4 * r4 + 3] = v.w;
+          }
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // every wave has read its slot
+      if (threadIdx.x == 0) __hip_atomic_store(flags_s + lb + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      zero_acc();
+    }
     read_half(ob, 0, F0);
 
     // k tile it + 2 of the piece, advanced without division while it is a gather tile
@@ -394,25 +457,33 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
       gc += wrap;
       return T;
     };
-    auto epi_request = [&]() {
+    // epilogue operand requests, slices [LO, HI) of 1 + MI * NI (ofx_planes.h)
+    auto epi_request = [&](auto lo_tag, auto hi_tag) {
+      constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;
       const int tid = opaque_tid();
       const int w = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
-      g2_epilogue_request<G2_WM, G2_WN, G2_MI, G2_NI>(g, (const void*)a.W2, P, m0, n0, w >> 1, w & 1, ln & 31, ln >> 5);
+      g2_static_for<HI - LO>([&](auto s_tag) {
+        g2_epilogue_request_slice<G2_WM, G2_WN, G2_MI, G2_NI, LO + decltype(s_tag)::value>(
+            g, (const void*)a.W2, P, m0, n0, w >> 1, w & 1, ln & 31, ln >> 5, b0w);
+      });
     };
     // One steady k-step.  On entry: F0 = first half of k tile `it` (reads possibly in flight), k tile it+1 requested.
-    auto step = [&](const Tile& T, auto last_tag) {
-      constexpr bool LAST = decltype(last_tag)::value;
+    // EPI slices [LO, HI) are requested in this step (LO == HI: none); their loads may stay in flight at its barrier.
+    auto step = [&](const Tile& T, auto lo_tag, auto hi_tag) {
+      constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;
+      constexpr bool LAST = HI > LO;
+      constexpr int NEPI = (LO < 1 && HI > 0 ? g2_epi_slice_loads<G2_NI>(0) : 0) + 4 * ((HI > 1 ? HI : 1) - (LO > 1 ? LO : 1));
       if constexpr (CF::NBUF == 3) {
         // table reads | wait F0 (4 younger) | {MFMA F0, read F1, request k tile it+2} | barrier | {MFMA F1, read F0'}
         load_idx(T, I);
         g2_wait_lgkm<4, PREC>(F0);
         G3_FENCE();
-        if (LAST) {
-          epi_request();
+        if constexpr (LAST) {
+          epi_request(lo_tag, hi_tag);
           G3_FENCE();
         }
         mfma_spliced(F0, true, ob, 1, F1, std::true_type(), T, obnn);
-        g2_wait_barrier<GLDS + (LAST ? G2_EPI_LOADS : 0), PREC>(F1);
+        g2_wait_barrier<GLDS + NEPI, PREC>(F1);
         G3_FENCE();
         mfma_spliced(F1, true, obn, 0, F0, std::false_type(), T, 0);
         const int t = ob; ob = obn; obn = obnn; obnn = t;
@@ -421,12 +492,12 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
         // buffer k tile `it` just left}
         g2_wait_lgkm<0, PREC>(F0);
         G3_FENCE();
-        if (LAST) {
-          epi_request();
+        if constexpr (LAST) {
+          epi_request(lo_tag, hi_tag);
           G3_FENCE();
         }
         mfma_spliced(F0, true, ob, 1, F1, std::false_type(), T, 0);
-        g2_wait_barrier<(LAST ? G2_EPI_LOADS : 0), PREC>(F1);
+        g2_wait_barrier<NEPI, PREC>(F1);
         G3_FENCE();
         load_idx(T, I);
         mfma_spliced(F1, true, obn, 0, F0, std::true_type(), T, ob);
@@ -452,16 +523,30 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
     };
 
     // ---- steady steps
-    bool first = true;
-    for (; it + 3 < k1; ++it) {
-      step(next_tile(), std::false_type());
-      if (first) {
-        first = false;
-        if (new_rows) raw_request(m0_n);                                // one more DMA, older than everything the next waits leave in flight
-      }
-    }
-    step(next_tile(), std::true_type());                                // it == k1 - 3: also requests the epilogue operands
+    // Steps [k0, k1 - 2): plain ones, then the ones that carry the epilogue requests -- one slice per step over the
+    // last NSL steps when the piece is long enough (each slice then has a step and a half to land, like a k tile),
+    // else all of them in the last step.
+    // Steps [k0, k1 - 2): plain ones, then NSP steps that carry the epilogue requests, one (or two) slices each: every
+    // slice has a step and a half to land, like a k tile, instead of 128 KB of residual rows arriving behind one wait.
+    // (ONE code path: a second, all-in-one-step path for short pieces made the register allocator spill the request
+    // registers -- and a compiler spill of an asm-loaded register can be stored before its data has landed.  Hence
+    // G3_KMIN = G3_NSP + 3: no piece is shorter.)
+    constexpr int NSL = 1 + G2_MI * G2_NI;                              // request slices (ofx_planes.h)
+    constexpr int NSP = NSL < G3_NSP ? NSL : G3_NSP;                    // steps they are spread over
+    typedef std::integral_constant<int, 0> Z0;
+    const int plain_end = k1 - 2 - NSP;                                 // >= k0 + 1
+    // (the first plain step always exists; written apart so that the compiler sees it on every path: its wait for
+    // accumulators that were initialised by loads then never lands in a later step, where it would drain the DMA queue)
+    step(next_tile(), Z0(), Z0());
     ++it;
+    if (new_rows) raw_request(m0_n);                                    // one more DMA, older than everything the next waits leave in flight
+    for (; it < plain_end; ++it) step(next_tile(), Z0(), Z0());
+    g2_static_for<NSP>([&](auto s_tag) {
+      constexpr int S = decltype(s_tag)::value;
+      constexpr int lo = S * NSL / NSP, hi = (S + 1) * NSL / NSP;       // an even share of the slices
+      step(next_tile(), std::integral_constant<int, lo>(), std::integral_constant<int, hi>());
+      ++it;
+    });
     if (new_rows) {
       // 3 stages: every wave read the old table before this step's barrier.  2 stages: the table reads sit in the
       // second half of the step -- meet once more before overwriting it.
@@ -482,46 +567,36 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
 
     // ---- the piece's result
     if (finisher) {
-      if (k1 < nkt) {
-        // pieces [k1, nkt) of this tile come from the blocks after this one; their pieces were their first work
+      if (cut_head && !early) {
+        // small layers (several blocks per tile): the other pieces are computed at the same time as this one, so they
+        // are added at the end, in ascending k order
         const unsigned u_tile_end = (t_cur + 1) * (unsigned)nkt;
         int nc = 0;
         for (int c = lb + 1; c < G && bound(c) < u_tile_end; ++c) ++nc;
-        if (threadIdx.x == 0) {
-          const unsigned long long tstart = g2_clock();
-          for (int c = lb + 1; c <= lb + nc; ++c) {
-            while (__hip_atomic_load(flags_s + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-              __builtin_amdgcn_s_sleep(8);
-              if (g2_clock() - tstart > (1ull << 33)) {                 // several seconds: give up, report, go on
-                __hip_atomic_store(flags_s + G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-              }
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        wait_flags(nc);
         for (int c = lb + 1; c <= lb + nc; ++c) {
           const char* src = reinterpret_cast<const char*>(part_s + (size_t)c * (G2_BM * G2_BN)) + opaque_tid() * 16;
           asm volatile("" : "+v"(src));                                  // keep the address arithmetic inside this branch
 #pragma unroll
-          for (int i = 0; i < G2_MI; ++i)
+          for (int i = 0; i < G2_MI; ++i) {
+            g2_v4f v[G2_NI][4];
 #pragma unroll
-            for (int j = 0; j < G2_NI; ++j) {
-              g2_v4f v[4];
+            for (int j = 0; j < G2_NI; ++j)
 #pragma unroll
               for (int r4 = 0; r4 < 4; ++r4) {
-                v[r4] = *reinterpret_cast<const g2_v4f*>(src);
+                v[j][r4] = *reinterpret_cast<const g2_v4f*>(src);
                 src += CF::THREADS * 16;
                 asm volatile("" : "+v"(src));
               }
 #pragma unroll
+            for (int j = 0; j < G2_NI; ++j)
+#pragma unroll
               for (int r4 = 0; r4 < 4; ++r4) {
-                acc[i][j][4 * r4 + 0] += v[r4].x; acc[i][j][4 * r4 + 1] += v[r4].y;
-                acc[i][j][4 * r4 + 2] += v[r4].z; acc[i][j][4 * r4 + 3] += v[r4].w;
+                acc[i][j][4 * r4 + 0] += v[j][r4].x; acc[i][j][4 * r4 + 1] += v[j][r4].y;
+                acc[i][j][4 * r4 + 2] += v[j][r4].z; acc[i][j][4 * r4 + 3] += v[j][r4].w;
               }
-              asm volatile("" ::: "memory");                             // four loads in flight at a time (registers)
-            }
+            asm volatile("" ::: "memory");                               // eight loads in flight at a time (registers)
+          }
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");    // every wave has read its slots
         if (threadIdx.x == 0)
@@ -531,8 +606,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
       {
         const int tid = opaque_tid();
         const int w = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
-        if (vec4) g2_epilogue_finish<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, P, m0, n0, w >> 1, w & 1, ln & 31, ln >> 5);
-        else epilogue_store_scalar<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, m0, n0, w >> 1, w & 1, ln & 31, ln >> 5, 0);
+        g2_epilogue_finish<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, P, m0, n0, w >> 1, w & 1, ln & 31, ln >> 5, emb_line);   // (vec4 only: host-checked)
       }
     } else {
       // a middle / tail piece: publish the raw accumulators (lane-linear float4 slabs), write-through
@@ -551,8 +625,13 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
             dst += CF::THREADS * 16;
             asm volatile("" : "+v"(dst));
           }
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // EVERY storing wave drains, then meet
-      if (threadIdx.x == 0) __hip_atomic_store(flags_s + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the flag follows once EVERY storing wave has drained and the block has met: that is what the next piece's
+      // first wait does anyway (a block's only piece: right here)
+      flag_pending = true;
+      if (!has_next) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (threadIdx.x == 0) __hip_atomic_store(flags_s + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     if (dbg) {
       if (dbg_piece < 6 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 5 + 2 * dbg_piece] = g2_clock();
@@ -602,12 +681,13 @@ static int g3_cus() {                  // compute units of the current device (c
 struct G3Plan { int G; unsigned q, rem, U; size_t part_bytes; };
 static bool g3_plan(int64_t M, int cout, int nkt, int wm, int ni, G3Plan& p) {
   const int cus = g3_cus();
-  if (cus < 8 || nkt < 7) return false;
+  if (cus < 8 || nkt < G3_KMIN) return false;
   const int64_t tiles = ofx_cdiv(M, wm * 64) * ofx_cdiv(cout, 64 * ni);
   const int64_t U = tiles * nkt;
-  if (U >= (1ll << 31) || U < 64) return false;
+  if (U >= (1ll << 31)) return false;
   int64_t slots = (int64_t)cus * (wm == 4 ? 1 : 2);
-  int64_t G = slots < U / 8 ? slots : U / 8;
+  // shares of >= 2 * G3_KMIN units: after snapping every piece still has >= G3_KMIN k-steps
+  int64_t G = slots < U / (2 * G3_KMIN) ? slots : U / (2 * G3_KMIN);
   G &= ~7ll;
   if (G < 8) return false;
   p.G = (int)G; p.U = (unsigned)U; p.q = (unsigned)(U / G); p.rem = (unsigned)(U % G);
@@ -623,6 +703,7 @@ int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, siz
   G3Plan p;
   GemmArgs& g = a.e;
   if (!sync || ((uintptr_t)sync & 3) || !ws_tail || ((uintptr_t)ws_tail & 15)) return 1;
+  if (!g.vec4) return 1;                   // (only the float4 epilogue exists in the persistent kernel)
   if (!g3_plan(g.M, (int)g.N, a.nkt, wm, ni, p)) return 1;
   if (p.part_bytes > ws_tail_bytes || (size_t)(p.G + 1) * sizeof(unsigned) > sync_bytes) return 1;
   if ((a.ldx >> 7) >= (1 << 20) || (a.ldt >> 7) >= (1 << 20) || a.n_src >= (1ll << 31)) return 1;
@@ -632,6 +713,7 @@ int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, siz
   A.b = a;
   A.G = p.G; A.q = p.q; A.rem = p.rem; A.U = p.U;
   A.part = (float*)ws_tail; A.flags = (unsigned*)sync;
+  A.early = p.q >= (unsigned)a.nkt + 2 * G3_KMIN ? 1 : 0;
   // last 16-B chunk that still starts inside the array (a chunk may run up to 12 B past the last entry: the caller
   // guarantees 16 B of readable slack behind nbr_ext, include/ofx.h)
   A.nbr_lim = (const char*)a.nbr_ext + ((((size_t)g.M * 28 - 4) >> 4) << 4);

@@ -38,7 +38,7 @@ template <int WM, int NI = 2> struct G2Cfg {
   static constexpr int LDS = PFS + 256;               // 155 904 B (WM 4) / 69 888 B (WM 2)
   static constexpr int B_PER_WAVE = (BN / 8) / WAVES;                 // weight-tile DMA instructions per wave: 1, 2 or 4
   static constexpr int READS = 2 * (G2_MI + NI);                      // LDS reads of one half-step fragment set
-  static constexpr int EPI_LOADS = G2_MI * NI * 4 + NI + G2_MI * 4;   // epilogue operand requests per lane (26 / 17)
+  static constexpr int EPI_LOADS = G2_MI * NI * 4 + NI + 1;          // epilogue operand requests per lane (19 / 10)
   static constexpr int GLDS = 4 + B_PER_WAVE;                         // DMA instructions per wave per k-step: 6 / 8
 };
 
@@ -174,7 +174,7 @@ template <int MI, int NI>
 struct G2Epi {
   g2_v4f res[MI][NI][4];
   g2_v4f bias[NI];
-  int bids[MI][4];
+  int bid;                   // batch id of row (wave's first row + lane): all 64 rows of the wave, one per lane
 };
 
 // The requests are inline asm: their NUMBER enters a counted s_waitcnt vmcnt(N) of the k-loop (the DMA of the next
@@ -187,35 +187,61 @@ __device__ __forceinline__ void g2_req32(int& d, const void* p) {
   asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p));
 }
 
-template <int WM, int WN, int MI, int NI>
-__device__ __forceinline__ void g2_epilogue_request(const GemmArgs& g, const void* dummy, G2Epi<MI, NI>& P, int64_t m0,
-                                                    int64_t n0, int wm, int wn, int l31, int h) {
+// The requests come in 1 + MI * NI slices so that a kernel may spread them over several k-steps (vmcnt is an in-order
+// counter: whatever is requested in one step has to land before the NEXT step's DMA can be consumed, so the residual
+// tile -- 128 KB per 256 x 128 tile, from HBM -- is better fetched 32 KB per step than all at once):
+//   slice 0             : the batch id of one of the wave's 64 rows per lane (1 dword load) and the bias / embedding
+//                         line of every column group (NI loads)
+//   slice 1 + i * NI + j: the residual rows of sub-tile (i, j) (4 loads)
+// b0w >= 0: batch element of the wave's first row, fetched ahead by the caller -- then a layer with a time embedding
+// and no bias gets the embedding row of that batch element in its bias slot (g2_epilogue_finish(..., emb_in_bias));
+// b0w < 0: the slot holds the bias only, the finish phase loads the embedding row itself.  (No load is issued here
+// for it: one compiler-visible VGPR load inside a k-step makes hipcc drain the whole DMA queue -- vmcnt(0) -- there.)
+template <int NI> constexpr int g2_epi_slice_loads(int slice) { return slice == 0 ? 1 + NI : 4; }
+template <int WM, int WN, int MI, int NI, int SLICE>
+__device__ __forceinline__ void g2_epilogue_request_slice(const GemmArgs& g, const void* dummy, G2Epi<MI, NI>& P,
+                                                          int64_t m0, int64_t n0, int wm, int wn, int l31, int h,
+                                                          int b0w = -1) {
   const int q = l31 & 3, k = l31 >> 2;
   const int64_t mw = m0 + wm * MI * 32;
   const int64_t mlast = g.M - 1;
-  const bool need_bid = g.emb || g.stats;
+  if constexpr (SLICE == 0) {
+    const bool need_bid = g.emb || g.stats;
+    {
+      int64_t m = mw + l31 + 32 * h;                         // lane l asks for row mw + l
+      m = m < mlast ? m : mlast;
+      g2_req32(P.bid, need_bid ? (const void*)(g.bid + m) : dummy);
+    }
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NI; ++j) {
+      int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
+      n = n < g.N ? n : g.N - 4;                             // clamped: out-of-range columns are never stored
+      // no bias but a time embedding (every conv1 of the U-Nets): the bias slot carries the embedding row of the
+      // wave's FIRST row's batch element -- the row a wave that lies inside one batch element adds to every output
+      // (g2_epilogue_finish checks that); the finish phase then has no load of its own to wait for
+      const void* bp = dummy;
+      if (g.bias) bp = g.bias + n;
+      else if (g.emb && b0w >= 0) bp = g.emb + (int64_t)b0w * g.lde + n;
+      g2_req128(P.bias[j], bp);
+    }
+  } else {
+    constexpr int i = (SLICE - 1) / NI, j = (SLICE - 1) % NI;
+    int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
+    n = n < g.N ? n : g.N - 4;
 #pragma unroll
     for (int G = 0; G < 4; ++G) {
       int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
       m = m < mlast ? m : mlast;
-      g2_req32(P.bids[i][G], need_bid ? (const void*)(g.bid + m) : dummy);
+      g2_req128(P.res[i][j][G], g.res ? (const void*)(g.res + m * g.ldr + n) : dummy);
     }
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
-    n = n < g.N ? n : g.N - 4;                               // clamped: out-of-range columns are never stored
-    g2_req128(P.bias[j], g.bias ? (const void*)(g.bias + n) : dummy);
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int G = 0; G < 4; ++G) {
-        int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
-        m = m < mlast ? m : mlast;
-        g2_req128(P.res[i][j][G], g.res ? (const void*)(g.res + m * g.ldr + n) : dummy);
-      }
   }
+}
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void g2_epilogue_request(const GemmArgs& g, const void* dummy, G2Epi<MI, NI>& P, int64_t m0,
+                                                    int64_t n0, int wm, int wn, int l31, int h, int b0w = -1) {
+  g2_static_for<1 + MI * NI>([&](auto s_tag) {
+    g2_epilogue_request_slice<WM, WN, MI, NI, decltype(s_tag)::value>(g, dummy, P, m0, n0, wm, wn, l31, h, b0w);
+  });
 }
 // after the vmcnt(0) of the last k-steps: ties every requested register to this point of the instruction stream
 __device__ __forceinline__ void g2_epilogue_landed(G2Epi<2, 2>& P) {
@@ -224,20 +250,18 @@ __device__ __forceinline__ void g2_epilogue_landed(G2Epi<2, 2>& P) {
                     "+v"(P.res[1][0][0]), "+v"(P.res[1][0][1]), "+v"(P.res[1][0][2]), "+v"(P.res[1][0][3]),
                     "+v"(P.res[1][1][0]), "+v"(P.res[1][1][1]), "+v"(P.res[1][1][2]), "+v"(P.res[1][1][3]),
                     "+v"(P.bias[0]), "+v"(P.bias[1]));
-  asm volatile("" : "+v"(P.bids[0][0]), "+v"(P.bids[0][1]), "+v"(P.bids[0][2]), "+v"(P.bids[0][3]),
-                    "+v"(P.bids[1][0]), "+v"(P.bids[1][1]), "+v"(P.bids[1][2]), "+v"(P.bids[1][3]));
+  asm volatile("" : "+v"(P.bid));
 }
 __device__ __forceinline__ void g2_epilogue_landed(G2Epi<2, 1>& P) {
   asm volatile("" : "+v"(P.res[0][0][0]), "+v"(P.res[0][0][1]), "+v"(P.res[0][0][2]), "+v"(P.res[0][0][3]),
                     "+v"(P.res[1][0][0]), "+v"(P.res[1][0][1]), "+v"(P.res[1][0][2]), "+v"(P.res[1][0][3]),
                     "+v"(P.bias[0]));
-  asm volatile("" : "+v"(P.bids[0][0]), "+v"(P.bids[0][1]), "+v"(P.bids[0][2]), "+v"(P.bids[0][3]),
-                    "+v"(P.bids[1][0]), "+v"(P.bids[1][1]), "+v"(P.bids[1][2]), "+v"(P.bids[1][3]));
+  asm volatile("" : "+v"(P.bid));
 }
 
 template <int WM, int WN, int MI, int NI>
 __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&acc)[MI][NI], G2Epi<MI, NI>& P, int64_t m0,
-                                                   int64_t n0, int wm, int wn, int l31, int h) {
+                                                   int64_t n0, int wm, int wn, int l31, int h, bool emb_in_bias = false) {
   const int q = l31 & 3, k = l31 >> 2;
   const bool q0 = q & 1, q1 = q & 2;
   const int64_t mw = m0 + wm * MI * 32;
@@ -247,20 +271,17 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
   if (g.emb || g.stats) {
     // batch id of the wave's first row = lane 0's first row (reading it here, not in the request phase, keeps a
     // scalarised load + wait out of the k-loop's tail)
-    b0 = __builtin_amdgcn_readfirstlane(P.bids[0][0]);
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int G = 0; G < 4; ++G) uni = uni && (P.bids[i][G] == b0);
-    uni = __all(uni);
+    b0 = __builtin_amdgcn_readfirstlane(P.bid);
+    uni = __all(P.bid == b0);                               // (rows past the end read the last row's id)
   }
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
     const bool ncol = n < g.N;
     const int64_t nc = ncol ? n : g.N - 4;
-    float4 eu = f4zero();
-    if (g.emb && uni) eu = *reinterpret_cast<const float4*>(g.emb + (int64_t)b0 * g.lde + nc);
+    g2_v4f euv = {0.f, 0.f, 0.f, 0.f};
+    if (g.emb && uni) euv = emb_in_bias ? P.bias[j] : *reinterpret_cast<const g2_v4f*>(g.emb + (int64_t)b0 * g.lde + nc);
+    const float4 eu = make_float4(euv.x, euv.y, euv.z, euv.w);
     const float4 bv = g.bias ? make_float4(P.bias[j].x, P.bias[j].y, P.bias[j].z, P.bias[j].w) : f4zero();
     float4 ssum = f4zero(), ssq = f4zero();
     int sb = -1;
@@ -287,11 +308,11 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
         float4 v = t[G];
         if (g.emb) {
           if (uni) f4add(v, eu);
-          else f4add(v, *reinterpret_cast<const float4*>(g.emb + (int64_t)P.bids[i][G] * g.lde + n));
+          else f4add(v, *reinterpret_cast<const float4*>(g.emb + (int64_t)g.bid[m] * g.lde + n));   // (a wave across two batch elements: rare)
         }
         if (g.res) f4add(v, make_float4(P.res[i][j][G].x, P.res[i][j][G].y, P.res[i][j][G].z, P.res[i][j][G].w));
         if (g.stats) {
-          const int b = P.bids[i][G];
+          const int b = uni ? b0 : g.bid[m];
           if (!uni && b != sb) {
             if (sb >= 0) flush(sb);
             ssum = f4zero(); ssq = f4zero();

@@ -61,3 +61,35 @@ def test_product_never_imports_oracle():
             if f.endswith('.py'):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), f
+
+
+def test_planes_kernels_have_no_scratch():
+    """The planes GraphConv kernels load registers with inline asm and count the waits by hand: a compiler spill of
+    such a register could be stored before its data has landed, and a spill reload inside a k-step makes hipcc drain the
+    DMA queue.  So the kernels must compile without scratch ('register budget')."""
+    import re
+    import subprocess
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from octfusion_amd import build
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+    def audit(src):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, 'k.s')
+            subprocess.run([hipcc] + build.FLAGS + ['-S', '--cuda-device-only', '-o', out, os.path.join(build.CSRC, src)],
+                           check=True, capture_output=True)
+            text = open(out).read()
+        rows = re.findall(r'\.name:\s+(\S*gconv\d_kernel\S*)\n(.*?)\.wavefront_size', text, re.S)
+        assert rows, src
+        bad = []
+        for name, body in rows:
+            priv = int(re.search(r'\.private_segment_fixed_size:\s+(\d+)', body).group(1))
+            spill = int(re.search(r'\.vgpr_spill_count:\s+(\d+)', body).group(1))
+            if priv or spill:
+                bad.append((name, priv, spill))
+        return len(rows), bad
+    with ThreadPoolExecutor(2) as ex:
+        res = list(ex.map(audit, ['ofx_gemm3.hip', 'ofx_gemm2.hip']))
+    assert res[0][0] == 8 and res[1][0] == 8, res          # 2 precisions x 2 geometries x 2 tile widths each
+    assert not res[0][1] and not res[1][1], res

@@ -272,9 +272,13 @@ def gather_microbench(doc, dev, C=128, iters=20):
             'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS}
 
 
+KERNEL_SOURCES = ('ofx_gemm3.hip', 'ofx_planes.h', 'ofx_gemm2.hip', 'ofx_gemm.hip', 'ofx_gemm_common.h')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r03', 'pmc_traffic.json')
+
+
 def kernel_source_hash():
     h = hashlib.sha256()
-    for f in ('ofx_gemm2.hip', 'ofx_gemm.hip', 'ofx_gemm_common.h'):
+    for f in KERNEL_SOURCES:
         h.update(open(os.path.join(ROOT, 'octfusion_amd', 'csrc', f), 'rb').read())
     return h.hexdigest()[:16]
 
@@ -445,7 +449,8 @@ def main():
         peak = {'bf16x3': MFMA_16BIT_PEAK_TFLOPS / 3.0, 'fp32': MFMA_F32_PEAK_TFLOPS, 'fp16': MFMA_16BIT_PEAK_TFLOPS}[bf]
         planes_kind = {'bf16x3': 'graph2', 'fp16': 'graph2h'}.get(bf)
         dom = profile_summary(prof, dt_prof, (planes_kind,), peak) if planes_kind else None
-        dom_name = ('gconv2_kernel<%d,5,*,*> (fused GraphConv on operand planes: LDS-DMA gather -> %s MFMA, fp32 accumulate)'
+        dom_name = ('gconv3_kernel<%d,*,*> (fused GraphConv on operand planes, persistent stream-K blocks: LDS-DMA gather '
+                    '-> %s MFMA, fp32 accumulate; gconv2_kernel for the layers too small for it)'
                     % ((2, 'bf16x3') if bf == 'bf16x3' else (1, 'fp16')))
         if dom is None:         # exact-fp32 mode / dense lr stage: the register-staged kernel carries the time
             dom = profile_summary(prof, dt_prof, ('graph', 'grid'), peak)
@@ -465,7 +470,7 @@ def main():
                          'frac': dom['hbm_frac'] if bound == 'hbm' else dom['mfma_frac'],
                          'traffic': None})
             roof.update(dom)
-            tpath = os.path.join(ROOT, 'profiles', 'r02', 'pmc_traffic.json')
+            tpath = PMC_FILE
             if os.path.exists(tpath):
                 try:
                     pj = json.load(open(tpath))
@@ -482,7 +487,7 @@ def main():
                         roof['traffic_source'] = pj.get('source')
                         roof['mfma_pmc'] = pj.get('mfma')
                     else:
-                        roof['traffic_note'] = ('profiles/r02/pmc_traffic.json was measured on kernel sources %s, this '
+                        roof['traffic_note'] = ('profiles/r03/pmc_traffic.json was measured on kernel sources %s, this '
                                                 'build is %s: not reported' % (pj.get('kernel_source_sha16'), kernel_source_hash()))
                 except Exception as e:      # noqa: BLE001
                     roof['traffic_note'] = 'pmc_traffic.json unreadable: %s' % e
@@ -546,6 +551,12 @@ def main():
             side('fp32_exact', 'fp32', False)
             res['fp32_ms_per_step'] = extras['fp32_exact']['ms_per_step']
             res['fp32_mfma_frac'] = extras['fp32_exact']['graphconv_mfma_frac']
+            # the same-arithmetic-as-the-reference figure as a peer of `value` (eager launches; `value` is graph replay)
+            res['value_fp32_exact'] = world * 1e3 / extras['fp32_exact']['ms_per_step']
+            res['roofline_fp32_exact'] = {'bound': 'mfma', 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                          'achieved': extras['fp32_exact']['graphconv_TFLOPs'],
+                                          'frac': extras['fp32_exact']['graphconv_mfma_frac'],
+                                          'kernel': 'gemm_fast_kernel<MODE_GATHER> (exact fp32 MFMA, register-staged)'}
             if args.precision == 'bf16x3' and wl.doc is not None:
                 side('bf16x3_register_staged_kernel', 'bf16x3', False)
                 side('fp16_single_pass', 'fp16', True)

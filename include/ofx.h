@@ -375,7 +375,8 @@ int ofx_planes_split(const float* x, int64_t ldx, int64_t n, int C, int Cpad, in
 int ofx_planes_merge(const void* planes, int64_t ldp_bytes, int64_t n, int C, int mode, float* out, int64_t ldo,
                      void* stream);
 int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id, const float* mean,
-                        const float* rstd, const float* w, const float* bias, int act, int mode, void* out,
+                        const float* rstd, const double* sums, const float* count, int groups, float eps,
+                        float count_eps, const float* w, const float* bias, int act, int mode, void* out,
                         int64_t ldo_bytes, const int32_t* seg_ptr, const int32_t* col, const int32_t* multi_seg,
                         int64_t n_multi, void* aux /* optional */, void* stream);
 int64_t ofx_planes_packed_ktiles(int cin, int nt, int mode);
@@ -456,13 +457,16 @@ int ofx_gather_mean(const float* x, int64_t ldx, int cin, int64_t n_nodes,
  *  finalize: mean/rstd [B, C] fp32 with inv_count = 1/(count*cpg + count_eps) and
  *            centred variance; count_eps = eps reproduces the reference (:302),
  *            count_eps = 0 is torch.nn.GroupNorm (GroupNorm32, modules.py:26-28).
- *  apply:    out = act((x - mean[b]) * rstd[b] * w + bias). */
+ *  apply:    out = act((x - mean[b]) * rstd[b] * w + bias);
+ *            mean / rstd from ofx_gn_finalize -- or both NULL, then (sums, count, groups, eps, count_eps) and the
+ *            launch finalises on the fly (same arithmetic, same bits; one launch less per norm). */
 int ofx_gn_stats(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,
                  int batch_size, double* sums, void* stream);
 int ofx_gn_finalize(const double* sums, const float* count, int batch_size, int C, int groups,
                     float eps, float count_eps, float* mean, float* rstd, void* stream);
 int ofx_gn_apply(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,
-                 const float* mean, const float* rstd, const float* w, const float* bias,
+                 const float* mean /* or NULL */, const float* rstd /* or NULL */, const double* sums /* if mean NULL */,
+                 const float* count, int groups, float eps, float count_eps, const float* w, const float* bias,
                  int act, float* out, int64_t ldo, void* stream);
 
 /* One-launch GroupNorm (+ activation) for layouts whose batch elements own `rows_per_batch` CONTIGUOUS rows (the

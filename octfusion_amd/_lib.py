@@ -99,8 +99,8 @@ _SIGS = {
                                 c_i, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_sz, c_p], True),
     'ofx_planes_split': (c_i, [c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_l, c_p], True),
     'ofx_planes_merge': (c_i, [c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p], True),
-    'ofx_gn_apply_planes': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_l,
-                                  c_p, c_p], True),
+    'ofx_gn_apply_planes': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_i, c_i, c_p,
+                                  c_l, c_p, c_p, c_p, c_l, c_p, c_p], True),
     'ofx_planes_packed_ktiles': (c_l, [c_i, c_i, c_i], False),
     'ofx_planes_packed_bytes': (c_l, [c_i, c_i, c_i, c_i], False),
     'ofx_pack_weights_planes': (c_i, [c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_p], True),
@@ -125,7 +125,7 @@ _SIGS = {
     'ofx_gather_mean': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p], True),
     'ofx_gn_stats': (c_i, [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_p], True),
     'ofx_gn_finalize': (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p], True),
-    'ofx_gn_apply': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p], True),
+    'ofx_gn_apply': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_i, c_p, c_l, c_p], True),
     'ofx_rows_copy': (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_p], True),
     'ofx_act': (c_i, [c_p, c_p, c_l, c_i, c_p], True),
     'ofx_timestep_embedding': (c_i, [c_p, c_i, c_i, c_f, c_p, c_p], True),

@@ -48,3 +48,15 @@ def stage_cfgs(name):
                              model_channels=p['model_channels'][i], channel_mult=p['channel_mult'][i],
                              num_res_blocks=p['num_res_blocks'][i], num_classes=p.get('num_classes'))
     return out
+
+
+# GraphVAE of each diffusion config (reference configs/vae_snet_eval.yaml:8-20 for ShapeNet;
+# configs/vae_obja_eval_depth864.yaml:8-20 is the depth-8 / stop-6 Objaverse VAE the depth-8/6/4 cascade decodes with)
+_VAE = dict(depth=8, channel_in=4, nout=4, full_depth=4, depth_stop=6, depth_out=8, resblk_type='basic', bottleneck=4,
+            resblk_num=2, code_channel=16, embed_dim=3)
+VAES = {'snet_uncond': _VAE, 'snet_cond': _VAE, 'obja_uncond': _VAE}
+
+
+def vae_params(name):
+    """kwargs for graph_vae.GraphVAE."""
+    return dict(VAES[name])

@@ -164,10 +164,33 @@ __device__ __forceinline__ unsigned gn_pk_bf16(float a, float b) {
   return r;
 }
 constexpr int GN_APPLY_ROWS = 64;
-template <int MODE>
+// (mean, rstd) of one (batch element, group) from the fp64 sums -- the arithmetic of gn_finalize_kernel, so a launch
+// that finalises on the fly (FIN) gives the same bits as ofx_gn_finalize + a launch that reads mean / rstd.
+struct GnFin { const double* sums; const float* count; int G; float eps, count_eps; };
+__device__ __forceinline__ void gn_group_stats(const GnFin& f, int b, int g, int C, float& mean, float& rstd) {
+  const int cpg = C / f.G;
+  double S = 0, SS = 0;
+  for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+    S += f.sums[((int64_t)b * C + c) * 2];
+    SS += f.sums[((int64_t)b * C + c) * 2 + 1];
+  }
+  const float cnt = f.count[b] * (float)cpg;
+  const float inv = 1.0f / (cnt + f.count_eps);
+  const double m = S * (double)inv;
+  const double ssd = SS - 2.0 * m * S + (double)cnt * m * m;
+  const double var = (ssd > 0 ? ssd : 0) * (double)inv;
+  mean = (float)m;
+  rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+}
+// FIN: no mean / rstd arrays -- the block derives them from the statistics sums itself (one launch less per norm:
+// the finalize kernel was 4.7 us + a launch boundary, 19 times per hr step).  The (mean, rstd) rows of the batch
+// elements of the block's first and last row are computed once per block into LDS; a row of any other batch element
+// (tiny graph levels, the aux blocks' scattered source rows) computes its four channels' groups directly.
+template <int MODE, bool FIN>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int C,
                                                        const int32_t* __restrict__ bid, const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, const float* __restrict__ w,
+                                                       const float* __restrict__ rstd, const GnFin fin,
+                                                       const float* __restrict__ w,
                                                        const float* __restrict__ bias, int act, char* __restrict__ out,
                                                        int64_t ldo, int64_t aux_blocks,
                                                        const int32_t* __restrict__ seg_ptr,
@@ -176,6 +199,27 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
                                                        char* __restrict__ aux) {
   const int CT = C >> 2, RP = 256 / CT;
   const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
+  __shared__ float fin_ms[FIN ? 2 * 2 * 1024 : 1];       // [slot][mean | rstd][C]
+  int fb0 = -1, fb1 = -1;
+  const bool is_aux = (int64_t)blockIdx.x < aux_blocks;
+  if (FIN && !is_aux) {
+    const int64_t r_begin = ((int64_t)blockIdx.x - aux_blocks) * GN_APPLY_ROWS;
+    const int64_t r_last = (r_begin + GN_APPLY_ROWS < n ? r_begin + GN_APPLY_ROWS : n) - 1;
+    fb0 = bid[r_begin];
+    fb1 = bid[r_last];
+    const int cpg = C / fin.G;
+    for (int t = threadIdx.x; t < 2 * fin.G; t += 256) {
+      const int slot = t / fin.G, g = t - slot * fin.G;
+      if (slot == 1 && fb1 == fb0) continue;
+      float mm, rr;
+      gn_group_stats(fin, slot ? fb1 : fb0, g, C, mm, rr);
+      for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) {
+        fin_ms[(slot * 2 + 0) * 1024 + cc] = mm;
+        fin_ms[(slot * 2 + 1) * 1024 + cc] = rr;
+      }
+    }
+    __syncthreads();
+  }
   if (rl >= RP) return;
   const int c = cl * 4;
   const float4 ww = *reinterpret_cast<const float4*>(w + c);
@@ -185,8 +229,26 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
   auto norm = [&](int b, const float4& v) {
     if (b != cb) {
       cb = b;
-      m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c);
-      rs = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c);
+      if (FIN) {
+        if (b == fb0 || b == fb1) {
+          const int slot = b == fb0 ? 0 : 1;
+          m = *reinterpret_cast<const float4*>(fin_ms + (slot * 2 + 0) * 1024 + c);
+          rs = *reinterpret_cast<const float4*>(fin_ms + (slot * 2 + 1) * 1024 + c);
+        } else {
+          const int cpg = C / fin.G;
+          float mm[4], rr[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (k == 0 || (c + k) / cpg != (c + k - 1) / cpg) gn_group_stats(fin, b, (c + k) / cpg, C, mm[k], rr[k]);
+            else { mm[k] = mm[k - 1]; rr[k] = rr[k - 1]; }
+          }
+          m = make_float4(mm[0], mm[1], mm[2], mm[3]);
+          rs = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        }
+      } else {
+        m = *reinterpret_cast<const float4*>(mean + (int64_t)b * C + c);
+        rs = *reinterpret_cast<const float4*>(rstd + (int64_t)b * C + c);
+      }
     }
     return make_float4(ofx_apply_act((v.x - m.x) * rs.x * ww.x + bb.x, act),
                        ofx_apply_act((v.y - m.y) * rs.y * ww.y + bb.y, act),
@@ -211,7 +273,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
       *reinterpret_cast<uint2*>(orow + c * 2) = o;
     }
   };
-  if ((int64_t)blockIdx.x < aux_blocks) {
+  if (is_aux) {
     // ---- aux rows of the consuming GraphConv (its multi-neighbour pre-pass, folded into this launch): aux[0] = the
     // zero row, aux[1 + v] = mean over segment multi_seg[v] of the NORMALISED source rows.  Reads the raw x (complete
     // before this launch), so it does not depend on the main blocks -- out must not alias x when aux is requested.
@@ -266,32 +328,50 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
   for (; r < r_end; r += RP) store(out + r * ldo, norm(bid[r], *reinterpret_cast<const float4*>(x + r * ldx + c)));
 }
 
+// mean / rstd: from ofx_gn_finalize -- or both NULL with (sums, count, groups, eps, count_eps): finalised on the fly.
+static bool gn_fin_args(const float* mean, const float* rstd, const double* sums, const float* count, int C, int groups,
+                        GnFin& f) {
+  if (mean || rstd) return mean && rstd && !(((uintptr_t)mean | (uintptr_t)rstd) & 15);
+  if (!sums || !count || groups < 1 || C % groups || C > 1024) return false;
+  f.sums = sums; f.count = count; f.G = groups;
+  return true;
+}
+
 extern "C" int ofx_gn_apply(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id, const float* mean,
-                            const float* rstd, const float* w, const float* bias, int act, float* out, int64_t ldo,
+                            const float* rstd, const double* sums, const float* count, int groups, float eps,
+                            float count_eps, const float* w, const float* bias, int act, float* out, int64_t ldo,
                             void* stream) {
-  if (!x || !batch_id || !mean || !rstd || !w || !bias || !out || n < 0 || C < 4 || (C & 3) || C > 1024 || ldx < C ||
+  GnFin f = {nullptr, nullptr, 1, eps, count_eps};
+  if (!x || !batch_id || !w || !bias || !out || n < 0 || C < 4 || (C & 3) || C > 1024 || ldx < C ||
       ldo < C || (ldx & 3) || (ldo & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)w & 15) ||
-      ((uintptr_t)bias & 15) || ((uintptr_t)mean & 15) || ((uintptr_t)rstd & 15) || act < 0 || act > 2)
+      ((uintptr_t)bias & 15) || act < 0 || act > 2 || !gn_fin_args(mean, rstd, sums, count, C, groups, f))
     return OFX_EINVAL;
   if (n > 0) {
     const int64_t mb = ofx_cdiv(n, GN_APPLY_ROWS);
-    gn_apply_kernel<0><<<(int)mb, 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, batch_id, mean, rstd, w, bias, act,
-                                                                (char*)out, ldo * 4, 0, nullptr, nullptr, nullptr, 0,
-                                                                nullptr);
+    if (mean)
+      gn_apply_kernel<0, false><<<(int)mb, 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, batch_id, mean, rstd, f, w, bias, act,
+                                                                         (char*)out, ldo * 4, 0, nullptr, nullptr,
+                                                                         nullptr, 0, nullptr);
+    else
+      gn_apply_kernel<0, true><<<(int)mb, 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, batch_id, nullptr, nullptr, f, w, bias,
+                                                                        act, (char*)out, ldo * 4, 0, nullptr, nullptr,
+                                                                        nullptr, 0, nullptr);
   }
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
 
 extern "C" int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,
-                                   const float* mean, const float* rstd, const float* w, const float* bias, int act,
+                                   const float* mean, const float* rstd, const double* sums, const float* count,
+                                   int groups, float eps, float count_eps, const float* w, const float* bias, int act,
                                    int mode, void* out, int64_t ldo_bytes, const int32_t* seg_ptr, const int32_t* col,
                                    const int32_t* multi_seg, int64_t n_multi, void* aux, void* stream) {
   const int chunk = mode == 2 ? 32 : 64;
-  if ((mode != 1 && mode != 2) || !x || !batch_id || !mean || !rstd || !w || !bias || !out || n < 0 || C < chunk ||
+  GnFin f = {nullptr, nullptr, 1, eps, count_eps};
+  if ((mode != 1 && mode != 2) || !x || !batch_id || !w || !bias || !out || n < 0 || C < chunk ||
       (C % chunk) || C > 1024 || ldx < C || (ldx & 3) || ldo_bytes < (int64_t)C * (mode == 2 ? 4 : 2) ||
       (ldo_bytes & 15) || ((uintptr_t)x & 15) || ((uintptr_t)out & 127) || ((uintptr_t)w & 15) ||
-      ((uintptr_t)bias & 15) || ((uintptr_t)mean & 15) || ((uintptr_t)rstd & 15) || act < 0 || act > 2)
+      ((uintptr_t)bias & 15) || act < 0 || act > 2 || !gn_fin_args(mean, rstd, sums, count, C, groups, f))
     return OFX_EINVAL;
   if (aux && (!seg_ptr || !col || n_multi < 0 || (n_multi > 0 && !multi_seg) || ((uintptr_t)aux & 127) ||
               (const void*)out == (const void*)x))
@@ -300,14 +380,13 @@ extern "C" int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C
     const int64_t mb = ofx_cdiv(n, GN_APPLY_ROWS);
     const int64_t ab = aux ? ofx_cdiv(n_multi + 1, 256 / (C >> 2)) : 0;      // one aux row per row lane
     const int grid = (int)(mb + ab);
-    if (mode == 2)
-      gn_apply_kernel<2><<<grid, 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, batch_id, mean, rstd, w, bias, act,
-                                                                (char*)out, ldo_bytes, ab, seg_ptr, col, multi_seg,
-                                                                n_multi, (char*)aux);
-    else
-      gn_apply_kernel<1><<<grid, 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, batch_id, mean, rstd, w, bias, act,
-                                                                (char*)out, ldo_bytes, ab, seg_ptr, col, multi_seg,
-                                                                n_multi, (char*)aux);
+    hipStream_t st = ofx_stream(stream);
+#define GN_GO(M_, F_)                                                                                              \
+  gn_apply_kernel<M_, F_><<<grid, 256, 0, st>>>(x, ldx, n, C, batch_id, mean, rstd, f, w, bias, act, (char*)out,   \
+                                                ldo_bytes, ab, seg_ptr, col, multi_seg, n_multi, (char*)aux)
+    if (mode == 2) { if (mean) GN_GO(2, false); else GN_GO(2, true); }
+    else { if (mean) GN_GO(1, false); else GN_GO(1, true); }
+#undef GN_GO
   }
   OFX_LAUNCH_CHECK();
   return OFX_OK;

@@ -74,6 +74,19 @@ def all_reduce_mean_(grads, bucket_bytes=256 << 20):
         return 0
     world = dist.get_world_size()
     keys = sorted(grads)
+    # ranks with different key sets / sizes would pack different flat buckets: an RCCL hang or silent corruption.
+    # One tiny all-reduce of (key count, total elements, a key-name checksum) turns that into an error.
+    import zlib
+    dev = grads[keys[0]].device if keys else torch.device('cpu')
+    sig = torch.tensor([len(keys), sum(grads[k].numel() for k in keys),
+                        sum(zlib.crc32(k.encode()) for k in keys) % (1 << 40)], dtype=torch.int64, device=dev)
+    lo, hi = sig.clone(), sig.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not torch.equal(lo, hi):
+        raise RuntimeError('all_reduce_mean_: the ranks hold different gradient sets (keys / sizes: min %s, max %s) -- a '
+                           'parameter without gradient on some rank must be zero-filled by the caller'
+                           % (lo.tolist(), hi.tolist()))
     total = 0
     bucket, size = [], 0
 

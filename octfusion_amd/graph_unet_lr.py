@@ -155,13 +155,14 @@ class GridConv3d(nn.Module):
         return depth + (0, -1, 1)[self.mode]
 
     @torch.no_grad()
-    def forward(self, x, gs, emb=None, res=None):
+    def forward(self, x, gs, emb=None, res=None, out=None):
+        """``out``: optional destination rows (may be a column slice of a wider buffer: zero-copy concatenation)."""
         d_out = self.out_depth(gs.depth)
         n_out = gs.B * 8 ** d_out
         bid = gs.cache.batch_id(d_out) if emb is not None else None
         mode = self.mode
         return ops.gridconv(x, lambda fast: gs.cache.table(mode, d_out, fast), n_out, self._pw.get(self.weight),
-                            self.bias, emb, bid, res)
+                            self.bias, emb, bid, res, out)
 
 
 class _PointConv(nn.Module):
@@ -176,9 +177,9 @@ class _PointConv(nn.Module):
         self._pw = ops.PackedWeight()
 
     @torch.no_grad()
-    def forward(self, x, res=None):
+    def forward(self, x, res=None, out=None):
         w = self.weight.view(self.weight.shape[0], self.weight.shape[1])
-        return ops.gemm(x, self._pw.get(w, 'nk'), self.bias, res)
+        return ops.gemm(x, self._pw.get(w, 'nk'), self.bias, res, out)
 
 
 class ConvUpsample(nn.Module):
@@ -189,8 +190,8 @@ class ConvUpsample(nn.Module):
         self.channels = channels
         self.conv = GridConv3d(channels, channels, mode=2)
 
-    def forward(self, x, gs):
-        return self.conv(x, gs), gs.at(gs.depth + 1)
+    def forward(self, x, gs, out=None):
+        return self.conv(x, gs, out=out), gs.at(gs.depth + 1)
 
 
 class ConvDownsample(nn.Module):
@@ -220,14 +221,14 @@ class ResnetBlock(nn.Module):
         self.res_conv = _PointConv(dim_in, dim_out, 3) if dim_in != dim_out else nn.Identity()
 
     @torch.no_grad()
-    def forward(self, x, emb_act, gs):
+    def forward(self, x, emb_act, gs, out=None):
         """emb_act = SiLU(time embedding) [B, emb_dim] (shared by all blocks of a step)."""
         h = self.block1[0](x, gs, act='silu')
         t = self.time_mlp[1](emb_act)                       # [B, dim_out]
         h = self.block1[2](h, gs, emb=t)                    # conv + bias + t[batch] fused
         h = self.block2[0](h, gs, act='silu', out=h)
         skip = x if isinstance(self.res_conv, nn.Identity) else self.res_conv(x)
-        return self.block2[3](h, gs, res=skip)
+        return self.block2[3](h, gs, res=skip, out=out)
 
 
 class QKVAttention(nn.Module):
@@ -249,17 +250,17 @@ class AttentionBlock(nn.Module):
             p.detach().zero_()
 
     @torch.no_grad()
-    def forward(self, x, gs):
+    def forward(self, x, gs, out=None):
         qkv = self.qkv(self.norm(x, gs))
         h = ops.attention(qkv, gs.B, 8 ** gs.depth, self.num_heads)
-        return self.proj_out(h, res=x)
+        return self.proj_out(h, res=x, out=out)
 
 
 class _AttnSeq(nn.Sequential):
     """Sequential(GroupNorm32, SiLU, AttentionBlock) of graph_unet_lr.py:128-132 (keys 0.*, 2.*)."""
 
-    def forward(self, x, gs):
-        return self[2](self[0](x, gs, act='silu'), gs)
+    def forward(self, x, gs, out=None):
+        return self[2](self[0](x, gs, act='silu'), gs, out=out)
 
 
 class LearnedSinusoidalPosEmb(nn.Module):
@@ -342,28 +343,50 @@ class UNet3DModel(nn.Module):
 
     @torch.no_grad()
     def forward_rows(self, x, batch_size, timesteps, label=None, as_middle=False):
-        """x [B*8^full_depth, C] in node-row layout; returns rows at full_depth."""
+        """x [B*8^full_depth, C] in node-row layout; returns rows at full_depth.  Runs under ops.POLICY['dense_net']
+        (default: exact fp32 -- this net is launch-bound, and bf16x3 here is where a whole step loses most accuracy)."""
+        with ops.policy_scope('dense_net'):
+            return self._forward_rows(x, batch_size, timesteps, label, as_middle)
+
+    def _forward_rows(self, x, batch_size, timesteps, label, as_middle):
         gs = GridState(batch_size, self.full_depth, x.device)
         if not as_middle:
             x = self.input_emb(x, gs)
         emb_act = self._embed(timesteps, label, batch_size)
 
-        def run_attn(m, x, gs):
-            return x if isinstance(m, our_Identity) else m(x, gs)
+        # Zero-copy skip concatenation (as the sparse net does): the decoder level that consumes the skip tensor of
+        # encoder level i reads ONE buffer [rows_i, C_x + C_skip]; the module that produces the skip writes its right
+        # columns and the module that produces x (mid_block2 / the previous level's upsampling conv) its left columns,
+        # so torch.cat (graph_unet_lr.py:210) never copies.  Level 0's skip is never consumed (the reference walks
+        # reversed(in_out[1:]), :152).
+        nlev = len(self.downs)
+        mc = self.model_channels
+        cout = [mc * m_ for m_ in self.channel_mult]                   # channels leaving encoder level i
+        bufs = {}
+        for i in range(1, nlev):
+            d_i = self.full_depth - min(i, nlev - 1)
+            bufs[i] = torch.empty(batch_size * 8 ** d_i, 2 * cout[i], dtype=torch.float32, device=x.device)
 
-        hs = []
-        for resnet, self_attn, downsample in self.downs:
-            x = run_attn(self_attn, resnet(x, emb_act, gs), gs)
-            hs.append(x)
+        def run_attn(m, x, gs, out=None):
+            return x if isinstance(m, our_Identity) else m(x, gs, out=out)
+
+        for i, (resnet, self_attn, downsample) in enumerate(self.downs):
+            slot = bufs[i][:, cout[i]:] if i in bufs else None
+            if isinstance(self_attn, our_Identity):
+                x = resnet(x, emb_act, gs, out=slot)
+            else:
+                x = run_attn(self_attn, resnet(x, emb_act, gs), gs, out=slot)
             if not isinstance(downsample, our_Identity):
                 x, gs = downsample(x, gs)
         x = self.mid_block1(x, emb_act, gs)
         x = run_attn(self.mid_self_attn, x, gs)
-        x = self.mid_block2(x, emb_act, gs)
-        for resnet, self_attn, upsample in self.ups:
-            x = torch.cat((x, hs.pop()), dim=1)
+        x = self.mid_block2(x, emb_act, gs, out=bufs[nlev - 1][:, :cout[nlev - 1]] if nlev > 1 else None)
+        for j, (resnet, self_attn, upsample) in enumerate(self.ups):
+            i = nlev - 1 - j                                            # the encoder level whose skip this level consumes
+            x = bufs[i]                                                 # = cat((x, skip_i), dim=1)
             x = run_attn(self_attn, resnet(x, emb_act, gs), gs)
-            x, gs = upsample(x, gs)
+            nxt = bufs[i - 1][:, :cout[i - 1]] if i - 1 in bufs else None
+            x, gs = upsample(x, gs, out=nxt)
         x = self.end[0](x, gs, act='silu')
         return x if as_middle else self.out(x, gs)
 
@@ -381,9 +404,15 @@ class UNet3DModel(nn.Module):
             'must specify label if and only if the model is class-conditional'
         B = x.shape[0]
         if not as_middle:
+            # cat((x, x_self_cond), dim=1) in row layout: both halves are written straight into one rows buffer
+            C = x.shape[1]
+            rows = torch.empty(B * 8 ** self.full_depth, 2 * C, dtype=torch.float32, device=x.device)
+            ops.voxel2octree_cf(x.float(), self.full_depth, out=rows[:, :C])
             if x_self_cond is None:
-                x_self_cond = torch.zeros_like(x)
-            x = torch.cat((x, x_self_cond), dim=1)
-        rows = ops.voxel2octree_cf(x.float(), self.full_depth)
+                rows[:, C:].zero_()
+            else:
+                ops.voxel2octree_cf(x_self_cond.float(), self.full_depth, out=rows[:, C:])
+        else:
+            rows = ops.voxel2octree_cf(x.float(), self.full_depth)
         y = self.forward_rows(rows, B, timesteps, label, as_middle)
         return ops.octree2voxel_cf(y, B, self.full_depth)

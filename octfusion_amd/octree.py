@@ -171,10 +171,14 @@ class Points:
         self.device = points.device
 
     def inbox_mask(self, min=-1.0, max=1.0):
-        return ((self.points >= min) & (self.points <= max)).all(dim=1)
+        """STRICTLY inside the box, as ocnn-pytorch's Points.inbox_mask (points > bbmin and points < bbmax; ocnn is
+        absent here -- parity at the ocnn boundary is unpinned, SURVEY 8c -- and this is its published behaviour): a
+        point ON a face of the cube is dropped, so no point ever lands outside the [0, 2^depth) cell range and the
+        clamp in ofx_points_keys never moves a point the reference's data path would have kept."""
+        return ((self.points > min) & (self.points < max)).all(dim=1)
 
     def clip(self, min=-1.0, max=1.0):
-        """keep the points inside [min, max]^3; returns the mask (index plumbing: one boolean gather per array)."""
+        """keep the points strictly inside (min, max)^3; returns the mask (index plumbing: one boolean gather per array)."""
         mask = self.inbox_mask(min, max)
         for name in ('points', 'normals', 'features', 'labels', 'batch_id'):
             v = getattr(self, name)

@@ -59,6 +59,33 @@ def get_precision():
     return [k for k, v in PRECISIONS.items() if v == code][0]
 
 
+# Precision policy of the DEFAULT mode ('bf16x3'): which parts of a step run in exact fp32 instead.  bf16x3 products
+# carry 16 significant bits per operand; through a whole denoising step that is ~10x the rounding noise of the
+# reference's own fp32 arithmetic (profiles/r03/oracle_fp32_noise.json, precision_attribution.json).  The parts that
+# are launch-bound anyway cost (almost) nothing in exact fp32:
+#   'dense_net' : the dense 16^3 / 8^3 / 4^3 U-Net (stage lr, and nested as the middle of stage hr) -- every GEMM,
+#                 27-tap convolution and 1x1 of it (its attention kernel is fp32 MFMA in every mode);
+#   'small_gemm': GEMMs / register-staged GraphConvs with <= 64 output or input channels (bf16x3 buys nothing there).
+# The wide GraphConvs (the planes kernel: > 95 % of the flops) stay bf16x3.  A policy entry of None follows the global
+# mode; the policy is ignored when the global mode is not 'bf16x3'.
+POLICY = {'dense_net': 'fp32', 'small_gemm': 'fp32'}
+
+
+@contextlib.contextmanager
+def policy_scope(part):
+    """Run the enclosed launches in POLICY[part] when the global mode is the default one."""
+    want = POLICY.get(part)
+    L = _lib.lib()
+    if want is None or L.ofx_get_precision() != PRECISIONS['bf16x3'] or want == 'bf16x3':
+        yield
+        return
+    call('ofx_set_precision', PRECISIONS[want])
+    try:
+        yield
+    finally:
+        call('ofx_set_precision', PRECISIONS['bf16x3'])
+
+
 # ---- operand planes (csrc/ofx_gemm2.hip): the LDS-DMA GraphConv and its producers --------------------
 PLANES_ATTR = '_ofx_planes'
 USE_PLANES = True            # A/B switch: False keeps every GraphConv on the register-staged kernel
@@ -318,8 +345,13 @@ def gemm(a, pw, bias=None, res=None, out=None, a_rows=None, out_rows=None, m=Non
     _chk(a_rows, torch.int32)
     _chk(out_rows, torch.int32)
     ws = workspace(a.device)
-    call('ofx_gemm_f32', ptr(a), lda, ptr(a_rows), M, pw.K, ptr(pw.t), pw.Kp, pw.N, ptr(bias),
-         ptr(res), ldr, ptr(out), ldc, ptr(out_rows), ptr(ws), ws.numel(), stream())
+    args = ('ofx_gemm_f32', ptr(a), lda, ptr(a_rows), M, pw.K, ptr(pw.t), pw.Kp, pw.N, ptr(bias),
+            ptr(res), ldr, ptr(out), ldc, ptr(out_rows), ptr(ws), ws.numel(), stream())
+    if pw.N <= 64 or pw.K <= 64:
+        with policy_scope('small_gemm'):
+            call(*args)
+    else:
+        call(*args)
     return out
 
 
@@ -372,11 +404,16 @@ def graphconv(x, nbr, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None
     if ext is not None and cin % 32 == 0:
         nbr_ext, multi_seg, n_multi = ext
         aux = torch.empty((n_multi + 1) * ldx, dtype=torch.float32, device=x.device)
-    call('ofx_graphconv_fwd', ptr(x), ldx, cin, N, ptr(nbr), ptr(seg_ptr), ptr(col), ptr(nbr_ext), ptr(multi_seg),
-         n_multi, ptr(aux), ptr(type_frac), ldt, nt_pad,
-         ptr(pw.t), pw.Kp, pw.N, ptr(bias), ptr(emb), lde,
-         ptr(batch_id) if (emb is not None or stats is not None) else None,
-         ptr(res), ldr, ptr(out), ldc, ptr(stats), pw.N, ptr(ws), ws.numel(), stream())
+    args = ('ofx_graphconv_fwd', ptr(x), ldx, cin, N, ptr(nbr), ptr(seg_ptr), ptr(col), ptr(nbr_ext), ptr(multi_seg),
+            n_multi, ptr(aux), ptr(type_frac), ldt, nt_pad,
+            ptr(pw.t), pw.Kp, pw.N, ptr(bias), ptr(emb), lde,
+            ptr(batch_id) if (emb is not None or stats is not None) else None,
+            ptr(res), ldr, ptr(out), ldc, ptr(stats), pw.N, ptr(ws), ws.numel(), stream())
+    if pw.N <= 64 or cin <= 64:
+        with policy_scope('small_gemm'):
+            call(*args)
+    else:
+        call(*args)
     if prof is not None:
         e1.record()
         E = col.numel()
@@ -597,8 +634,6 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         call('ofx_gn_fused_rows', ptr(x), ldx, rows_per_batch, batch_size, C, groups, eps, count_eps,
              ptr(weight.detach().reshape(-1)), ptr(bias.detach().reshape(-1)), ACT[act], ptr(out), ldo, stream())
         return out
-    mean = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
-    rstd = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
     if stats is not None:
         _chk(stats, torch.float64)
         assert stats.numel() == batch_size * C * 2
@@ -606,8 +641,7 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
     else:
         sums = torch.empty(batch_size * C * 2, dtype=torch.float64, device=dev)
         call('ofx_gn_stats', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
-    call('ofx_gn_finalize', ptr(sums), ptr(count), batch_size, C, groups, eps, count_eps, ptr(mean), ptr(rstd),
-         stream())
+    # mean / rstd are derived from the sums inside the apply launch (ofx.h): no ofx_gn_finalize launch
     w = weight.detach().reshape(-1)
     b = bias.detach().reshape(-1)
     if planes:
@@ -622,8 +656,9 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         if aux_graph is not None:
             seg_ptr, col, multi_seg, n_multi = aux_graph
             aux = torch.empty((n_multi + 1) * ldo, dtype=torch.uint8, device=dev)
-        call('ofx_gn_apply_planes', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(w), ptr(b),
-             ACT[act], planes, ptr(out), ldo, ptr(seg_ptr), ptr(col), ptr(multi_seg), n_multi, ptr(aux), stream())
+        call('ofx_gn_apply_planes', ptr(x), ldx, n, C, ptr(batch_id), None, None, ptr(sums), ptr(count), groups, eps,
+             count_eps, ptr(w), ptr(b), ACT[act], planes, ptr(out), ldo, ptr(seg_ptr), ptr(col), ptr(multi_seg), n_multi,
+             ptr(aux), stream())
         setattr(out, PLANES_ATTR, planes)
         if aux is not None:
             setattr(out, AUX_ATTR, aux)
@@ -632,8 +667,8 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         out = torch.empty(n, C, dtype=torch.float32, device=dev)
     out2, ldo = _row_major(out)
     assert out2 is out
-    call('ofx_gn_apply', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(w), ptr(b),
-         ACT[act], ptr(out), ldo, stream())
+    call('ofx_gn_apply', ptr(x), ldx, n, C, ptr(batch_id), None, None, ptr(sums), ptr(count), groups, eps, count_eps,
+         ptr(w), ptr(b), ACT[act], ptr(out), ldo, stream())
     return out
 
 

@@ -32,61 +32,145 @@ class CascadeSampler:
         self.df_type = list(cfg['df_type'])
         self.depths = list(cfg['input_depth'])
 
-    @torch.no_grad()
     def _seed(self, value):
         torch.manual_seed(value)
         if torch.cuda.is_available():
             torch.cuda.manual_seed(value)
 
+    # ---- per-shape noise streams -------------------------------------------------------------------------------
+    # The reference generates ONE shape per call and seeds the global RNG per shape (train.py:166-185 ->
+    # octfusion_model_union.py:372,390: seed + save_index before the lr loop, seed before the hr loop; the 3-stage
+    # model never reseeds).  A batch of shapes reproduces that exactly if every shape draws from its own generator
+    # in the order the reference's loop would: initial noise, then one tensor per x0-branch step that uses noise.
+    def _gen(self, seed):
+        g = torch.Generator(device=self.device)
+        g.manual_seed(int(seed))
+        return g
+
+    def _dense_noise(self, gens, shape1, ddim_steps, df_type, truncated):
+        """(init [B, ...], step list) for a dense stage from per-shape generators."""
+        init = torch.cat([torch.randn(shape1, generator=g, device=self.device) for g in gens])
+        steps = [None] * ddim_steps
+        if df_type == 'x0':
+            # the reference evaluates randn_like on EVERY x0-branch step (torch.where picks it or zeros,
+            # octfusion_model_union.py:338-343): the stream advances even where the draw is dropped
+            for i, (_, t_next) in enumerate(sampler.sampling_times(ddim_steps)):
+                draw = torch.cat([torch.randn(shape1, generator=g, device=self.device) for g in gens])
+                if bool(t_next > truncated):
+                    steps[i] = draw
+        return init, steps
+
+    def _node_noise(self, gens, doctree, depth, channels, ddim_steps, df_type):
+        """The same for a sparse stage: shape b's rows of the batched tensor (all depth blocks, in order) are exactly
+        the rows of the tensor a batch-of-one doctree of that shape has, so its noise is drawn at that size and
+        scattered to its rows."""
+        bid = doctree.batch_id32(depth).long()
+        order = torch.argsort(bid, stable=True)
+        counts = torch.bincount(bid, minlength=doctree.batch_size).tolist()
+
+        def draw():
+            out = torch.empty(bid.shape[0], channels, dtype=torch.float32, device=self.device)
+            out[order] = torch.cat([torch.randn(n, channels, generator=g, device=self.device)
+                                    for g, n in zip(gens, counts)])
+            return out
+        init = draw()
+        steps = [None] * ddim_steps
+        if df_type == 'x0':
+            for i in range(ddim_steps):
+                steps[i] = draw()
+        return init, steps
+
+    @torch.no_grad()
     def sample(self, batch_size, ddim_steps=200, label=None, split_small=None, noises=None, sdf_resolution=None,
-               sdf_scale=0.9, use_graph=None, seed=None, save_index=0):
+               sdf_scale=0.9, use_graph=None, seed=None, save_index=0, shape_indices=None, timings=None):
         """Returns a dict with the per-stage results.  `noises` (optional) = dict of explicit
         init / step noise tensors per stage for reproducible runs.  sdf_resolution (e.g. 256) adds
         out['sdfs'] [B, R, R, R] (needs the VAE).
         seed / save_index: the reference's per-shape seeding of the 2-stage model -- seed_everything(seed +
         save_index) before the lr loop, seed_everything(seed) before the hr loop (octfusion_model_union.py:372,390);
-        the 3-stage model does not reseed (octfusion_model_union_3t.py:168,184,204: commented out)."""
-        noises = noises or {}
+        the 3-stage model does not reseed (octfusion_model_union_3t.py:168,184,204: commented out).
+        shape_indices (list of batch_size result indices, needs seed): every shape of the batch gets the noise the
+        reference's one-shape-per-call loop would draw for that result index -- a batch of shapes generates what
+        batch_size calls with save_index = shape_indices[b] would.
+        timings (optional dict): filled with seconds per phase (host-synchronised: adds a few syncs)."""
+        import time as _time
+        noises = dict(noises or {})
         out = {}
         S = 1 << self.full_depth
-        reseed = seed is not None and len(self.stages) == 2
+        two_stage = len(self.stages) == 2
+        reseed = seed is not None and two_stage
+        gens = None
+        if shape_indices is not None:
+            assert seed is not None and len(shape_indices) == batch_size
+            gens = [self._gen(seed + int(i)) for i in shape_indices]
+
+        def lap(name, t0):
+            if timings is not None:
+                if self.device.type == 'cuda':
+                    torch.cuda.synchronize()
+                timings[name] = timings.get(name, 0.0) + _time.perf_counter() - t0
+            return _time.perf_counter()
+        t0 = lap('_start', _time.perf_counter())
         if split_small is None:
-            if seed is not None:
+            if gens is not None and 'lr' not in noises:
+                init, steps = self._dense_noise(gens, (1, self.cfg['input_channels'][0], S, S, S), ddim_steps,
+                                                self.df_type[0], sampler.TRUNCATED_TIME)
+                noises['lr'] = {'init': init, 'steps': steps}
+            elif seed is not None:
                 self._seed(seed + save_index if reseed else seed)
             n = noises.get('lr', {})
             split_small = sampler.sample_loop(
                 self.net, (batch_size, self.cfg['input_channels'][0], S, S, S), batch_size, ddim_steps, 'lr',
                 self.df_type[0], self.device, label=label, truncated_index=sampler.TRUNCATED_TIME,
                 init_noise=n.get('init'), step_noise=n.get('steps'), use_graph=use_graph)
+            t0 = lap('lr_steps', t0)
         out['split_small'] = split_small
         octree = split2octree_small(split_small, self.depths[1], self.full_depth)
         out['octree_small'] = octree
         if len(self.stages) < 2:
             return out
         doctree = DualOctree(octree)
-        n = noises.get('hr', {})
-        if reseed:
+        t0 = lap('octree_and_graph', t0)
+        if gens is not None and 'hr' not in noises:
+            if two_stage:
+                gens = [self._gen(seed) for _ in shape_indices]          # :390 -- the SAME seed for every shape
+            init, steps = self._node_noise(gens, doctree, self.depths[1], self.cfg['input_channels'][1], ddim_steps,
+                                           self.df_type[1])
+            noises['hr'] = {'init': init, 'steps': steps}
+        elif reseed:
             self._seed(seed)
+        n = noises.get('hr', {})
         x = sampler.sample_loop(self.net, (doctree.total_num, self.cfg['input_channels'][1]), batch_size, ddim_steps,
                                 'hr', self.df_type[1], self.device, doctree=doctree, unet_lr=self.net.unet_lr,
                                 label=label, init_noise=n.get('init'), step_noise=n.get('steps'), use_graph=use_graph)
         out['hr'] = x
+        t0 = lap('hr_steps', t0)
         if len(self.stages) >= 3:
             nn6 = int(octree.nnum[self.depths[1]])
             split_large = x[x.shape[0] - nn6:].contiguous()
             octree = split2octree_large(octree, split_large, self.depths[1])
             out['octree_large'] = octree
             doctree = DualOctree(octree)
+            t0 = lap('octree_and_graph', t0)
+            if gens is not None and 'feature' not in noises:
+                init, steps = self._node_noise(gens, doctree, self.depths[2], self.cfg['input_channels'][2],
+                                               ddim_steps, self.df_type[2])
+                noises['feature'] = {'init': init, 'steps': steps}
             n = noises.get('feature', {})
             x = sampler.sample_loop(self.net, (doctree.total_num, self.cfg['input_channels'][2]), batch_size,
                                     ddim_steps, 'feature', self.df_type[2], self.device, doctree=doctree,
                                     unet_lr=self.net.unet_hr, label=label, init_noise=n.get('init'),
                                     step_noise=n.get('steps'), use_graph=use_graph)
             out['feature'] = x
+            t0 = lap('feature_steps', t0)
         out['doctree'] = doctree
         if self.vae is not None:
             out['decoded'] = self.vae.decode_code(x, doctree)
+            t0 = lap('vae_decode', t0)
             if sdf_resolution:
                 out['sdfs'] = mpu.calc_sdf(out['decoded']['neural_mpu'], batch_size, size=sdf_resolution,
                                            bbmin=-sdf_scale, bbmax=sdf_scale)
+                t0 = lap('sdf', t0)
+        if timings is not None:
+            timings.pop('_start', None)
         return out

@@ -14,11 +14,37 @@ from ._lib import call, ptr, stream
 class AdamW:
     """torch.optim.AdamW (the reference's optimiser, octfusion_model_union.py:142) on ofx_adamw_step."""
 
-    def __init__(self, named_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, named_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, sync=True):
         self.params = dict(named_params)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.state = {k: (torch.zeros_like(p.data), torch.zeros_like(p.data)) for k, p in self.params.items()}
+        if sync:
+            self.sync_()
+
+    @torch.no_grad()
+    def sync_(self, src=0):
+        """Under torch.distributed: every rank takes rank `src`'s parameters and optimiser state (what wrapping the net
+        in DistributedDataParallel does at construction for the reference, octfusion_model_union.py:185-196) -- ranks
+        that were seeded differently would otherwise average gradients of different models, silently."""
+        import torch.distributed as td
+        if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+            return 0
+        keys = sorted(self.params)
+        tensors = [self.params[k].data for k in keys] + [s for k in keys for s in self.state[k]]
+        flat = torch.cat([t_.reshape(-1).float() for t_ in tensors])
+        td.broadcast(flat, src=src)
+        off = 0
+        for t_ in tensors:
+            n = t_.numel()
+            t_.copy_(flat[off:off + n].view_as(t_))
+            off += n
+        for k in keys:
+            _bump(self.params[k])
+        step = torch.tensor([self.step_count], dtype=torch.int64, device=flat.device)
+        td.broadcast(step, src=src)
+        self.step_count = int(step.item())
+        return flat.numel() * 4
 
     @torch.no_grad()
     def step(self, grads):

@@ -11,6 +11,26 @@ import math
 import torch
 import torch.nn.functional as F
 
+# Working float type of the spots where the reference says `.float()` (GroupNorm32, modules.py:26-28; the softmax of
+# QKVAttention, :546; the timestep embedding).  float32 = the reference.  Tests that need an error figure for an
+# fp32-class implementation below the fp32 reference's own rounding noise run the SAME op sequence in float64
+# (`with oracle.modules.working_float(torch.float64)`, all tensors passed as doubles).
+FLOAT = torch.float32
+
+
+class working_float:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global FLOAT
+        self.saved, FLOAT = FLOAT, self.dtype
+
+    def __exit__(self, *exc):
+        global FLOAT
+        FLOAT = self.saved
+
+
 from .octree import scatter_add
 
 
@@ -93,7 +113,7 @@ def pool_rearrange(x, doctree, d, down_w):
     lnumd = int(doctree.lnum[d - 1])
     leaf_mask = doctree.node_child(d - 1) < 0
     outd = downsample(x[-numd:], down_w)
-    out = torch.zeros(leaf_mask.shape[0], x.shape[1])
+    out = torch.zeros(leaf_mask.shape[0], x.shape[1], dtype=x.dtype)
     out[leaf_mask] = x[-lnumd - numd:-numd]
     out[leaf_mask.logical_not()] = outd
     return torch.cat([x[:-numd - lnumd], out], dim=0)
@@ -183,7 +203,7 @@ def graph_resblocks(x, doctree, depth, sd, n_node_type):
 # ---- dense (16^3 voxel) blocks: modules.py:26-95, 474-563 -------------------
 
 def group_norm32(x, w, b, channels):
-    return F.group_norm(x.float(), min(channels, 32), w, b, 1e-5)
+    return F.group_norm(x.to(FLOAT), min(channels, 32), w, b, 1e-5)
 
 
 def resnet_block(x, emb, sd):
@@ -213,7 +233,7 @@ def attention_block(x, sd, num_heads):
     q, k, v = torch.split(qkv, ch, dim=1)
     scale = 1 / math.sqrt(math.sqrt(ch))
     w = torch.einsum('bct,bcs->bts', q * scale, k * scale)
-    w = torch.softmax(w.float(), dim=-1)
+    w = torch.softmax(w.to(FLOAT), dim=-1)
     h = torch.einsum('bts,bcs->bct', w, v).reshape(b, -1, x.shape[-1])
     h = F.conv1d(h, sd['proj_out.weight'], sd['proj_out.bias'])
     return (x + h).reshape(b, c, *spatial)

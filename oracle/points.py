@@ -23,7 +23,7 @@ def build_octree(points, normals, depth, full_depth):
     scale = 2 ** (depth - 1)
     pts = (points + 1.0) * scale
     hi = 2 ** depth - 1
-    ijk = pts.long().clamp(0, hi)          # p == +1.0 stays in the last cell (ocnn's clip keeps it)
+    ijk = pts.long().clamp(0, hi)          # (clipped inputs lie strictly inside the cube: the clamp never acts on them)
     key = xyz2key(ijk[:, 0], ijk[:, 1], ijk[:, 2], None, depth)
     node_key, idx, counts = torch.unique(key, sorted=True, return_inverse=True, return_counts=True)
     for d in range(full_depth + 1):

@@ -19,8 +19,8 @@ from .octree import octree2voxel
 def timestep_embedding(timesteps, dim, max_period=10000):
     """ldm_diffusion_util.py:171-191."""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
-    args = timesteps[:, None].float() * freqs[None]
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=M.FLOAT) / half)
+    args = timesteps[:, None].to(M.FLOAT) * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
         emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)

@@ -147,3 +147,63 @@ def test_committed_bench_lines_follow_the_contract():
         for k in ('value', 'unit', 'cores', 'kind', 'sample'):
             assert k in c, (wl, k)
         assert c['kind'] in ('port', 'reference')
+
+
+def _gen_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from octfusion_amd import dist as D, generate as G
+    D.init(backend='gloo')
+    # every rank but 0 starts from its own constructor weights; prepare() must leave rank 0's U-Net AND VAE everywhere
+    torch.manual_seed(7 + rank)
+    net, vae, nbytes = G.prepare('snet_uncond', rank, torch.device('cpu'))
+
+    def digest(m):
+        return torch.stack([p.detach().double().sum() for p in m.parameters()] +
+                           [p.detach().double().abs().sum() for p in m.parameters()])
+    dig = torch.cat([digest(net), digest(vae)])
+    gathered = [torch.zeros_like(dig) for _ in range(world)]
+    dist.all_gather(gathered, dig)
+    groups = G.plan(11, rank, world, 3)
+    all_groups = [None] * world
+    dist.all_gather_object(all_groups, groups)
+    D.barrier()
+    if rank == 0:
+        n_par = sum(p.numel() for p in net.parameters()) + sum(p.numel() for p in vae.parameters())
+        n_buf = sum(b.numel() for m in (net, vae) for b in m.buffers() if b.is_floating_point())
+        torch.save({'same': all(torch.equal(gathered[0], g) for g in gathered), 'nbytes': nbytes,
+                    'numel': n_par + n_buf, 'groups': all_groups, 'nonzero': float(dig.abs().sum()) > 0}, out)
+    dist.destroy_process_group()
+
+
+def test_generate_prepare_world2(tmp_path):
+    """The generate driver on two ranks (gloo): U-Net and VAE weights of rank 0 reach every rank in the one broadcast
+    per model, and the ranks' index groups are the reference's rank-strided result indices (train.py:168), batched."""
+    out = str(tmp_path / 'g.pt')
+    mp.spawn(_gen_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r['same'] and r['nonzero']
+    assert r['nbytes'] == 4 * r['numel']
+    assert r['groups'] == [[[0, 2, 4], [6, 8, 10]], [[1, 3, 5], [7, 9]]]
+
+
+def test_generate_samples_with_ema_weights(tmp_path):
+    """A checkpoint whose df_* and ema_df_* sets differ: the sampling net must hold the EMA set (train.py:181,
+    octfusion_model_union.py:319,391)."""
+    sys.path.insert(0, ROOT)
+    from octfusion_amd import checkpoint, configs, generate as G
+    from octfusion_amd.graph_unet_union import UNet3DModel
+    torch.manual_seed(1)
+    df = UNet3DModel(**configs.unet_params('snet_uncond', 'hr'))
+    ema = UNet3DModel(**configs.unet_params('snet_uncond', 'hr'))
+    with torch.no_grad():
+        for p in ema.parameters():
+            p.add_(0.25)
+    path = str(tmp_path / 'df_steps-latest.pth')
+    checkpoint.save_ckpt(path, df, ema, global_step=3, stage_flag='hr')
+    net, _ = G.build_models('snet_uncond', ckpt=path, with_vae=False)
+    want, have, other = ema.state_dict(), net.state_dict(), df.state_dict()
+    assert list(want) == list(have)
+    assert all(torch.equal(want[k], have[k]) for k in want)
+    assert not all(torch.equal(other[k], have[k]) for k in want)

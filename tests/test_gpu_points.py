@@ -75,10 +75,13 @@ def test_build_octree_roundtrip_and_edges():
         same_octree(oc2, ref)
         close(oc2.get_input_feature('ND'), feat_ref, 1e-5)
     # Points.clip drops what lies outside the cube before the build (datasets/dualoctree_snet.py:45)
-    p = Points(torch.tensor([[0.0, 0.0, 0.0], [1.5, 0.0, 0.0], [0.2, -1.01, 0.1]]).to(dev()),
-               torch.tensor([[1.0, 0.0, 0.0]] * 3).to(dev()))
+    # -- strictly: a point ON a face of the cube goes too (ocnn's inbox_mask is points > min and points < max)
+    p = Points(torch.tensor([[0.0, 0.0, 0.0], [1.5, 0.0, 0.0], [0.2, -1.01, 0.1], [1.0, 0.0, 0.0], [0.3, -1.0, 0.2],
+                             [0.999999, -0.999999, 0.5]]).to(dev()),
+               torch.tensor([[1.0, 0.0, 0.0]] * 6).to(dev()))
     mask = p.clip(-1.0, 1.0)
-    assert mask.tolist() == [True, False, False] and p.points.shape[0] == 1 and p.normals.shape[0] == 1
+    assert mask.tolist() == [True, False, False, False, False, True]
+    assert p.points.shape[0] == 2 and p.normals.shape[0] == 2
 
 
 def test_vae_encoder_runs_on_built_octree():

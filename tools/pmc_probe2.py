@@ -1,5 +1,5 @@
-"""Tiny workload for rocprofv3 --pmc passes over the planes GraphConv (gconv2_kernel): a few launches of the bench's
-heaviest layers, both geometries.  Counters are collected in separate passes (FETCH_SIZE; WRITE_SIZE;
+"""Tiny workload for rocprofv3 --pmc passes over the planes GraphConv (gconv3_kernel, the persistent launch): a few
+launches of the bench's heaviest layers.  Counters are collected in separate passes (FETCH_SIZE; WRITE_SIZE;
 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ...; GRBM_GUI_ACTIVE) and summarised by tools/pmc_summary.py."""
 import os
 import sys
@@ -13,13 +13,14 @@ from octfusion_amd.octree import split2octree_small
 
 dev = torch.device('cuda:0')
 torch.set_grad_enabled(False)
-doc = DualOctree(split2octree_small(synthetic.shell6_split(8).to(dev), 6, 4))
+doc = DualOctree(split2octree_small(synthetic.shell6_split(8, jitter=True).to(dev), 6, 4))
 ops.PLANES_MIN_TILES = 1
 for d, cin, cout in [(6, 128, 128), (5, 256, 256), (6, 384, 128), (5, 512, 512)]:
     N = doc.csr(d)[2]
     conv = M.GraphConv(cin, cout, 7, 7, d - 1).to(dev)
     conv.emit_stats = False
-    xp = ops.planes_split(torch.randn(N, cin, device=dev), 2)
+    gn = M.DualOctreeGroupNorm(cin).to(dev)
+    xp = gn(torch.randn(N, cin, device=dev), doc, d, act='silu', planes=2)      # planes + aux rows (no pre-pass launch)
     res = torch.randn(N, cout, device=dev)
     emb = torch.randn(8, cout, device=dev)
     for _ in range(4):

@@ -1,4 +1,4 @@
-"""Summarise the rocprofv3 --pmc passes over tools/pmc_probe2.py into profiles/r02/pmc_traffic.json.
+"""Summarise the rocprofv3 --pmc passes over tools/pmc_probe2.py into profiles/r03/pmc_traffic.json.
 
     python tools/pmc_summary.py <dir with <pass>/p_counter_collection.csv> <out.json>
 Passes (one rocprofv3 run each: counters of different blocks do not share a pass reliably):
@@ -22,7 +22,7 @@ per = {}
 for f in glob.glob(os.path.join(src, '*', '*counter_collection.csv')):
     byd = {}
     for r in csv.DictReader(open(f)):
-        if 'gconv2_kernel' in r['Kernel_Name']:
+        if 'gconv3_kernel' in r['Kernel_Name']:
             byd.setdefault(int(r['Dispatch_Id']), []).append(r)
     ids = sorted(byd)
     assert len(ids) == 4 * len(LAYERS), (f, len(ids))
@@ -34,12 +34,12 @@ for f in glob.glob(os.path.join(src, '*', '*counter_collection.csv')):
             d['kernel'], d['grid'] = r['Kernel_Name'].split('(')[0], int(r['Grid_Size'])
 mean = lambda v: sum(v) / len(v)
 h = hashlib.sha256()
-for f in ('ofx_gemm2.hip', 'ofx_gemm.hip', 'ofx_gemm_common.h'):
+for f in ('ofx_gemm3.hip', 'ofx_planes.h', 'ofx_gemm2.hip', 'ofx_gemm.hip', 'ofx_gemm_common.h'):
     h.update(open(os.path.join(ROOT, 'octfusion_amd', 'csrc', f), 'rb').read())
 out = {'kernel_source_sha16': h.hexdigest()[:16], 'workload': 'hr',
        'source': 'rocprofv3 --pmc, one pass per counter group, over tools/pmc_probe2.py on MI355X: 4 launches per layer '
-                 'of gconv2_kernel (planes GraphConv with emb + residual epilogue), shell-6 B=8; raw rows in '
-                 'profiles/r02/pmc_*_probe2.csv',
+                 'of gconv3_kernel (persistent planes GraphConv with emb + residual epilogue), shell-6 B=8; raw rows '
+                 'in profiles/r03/pmc_*_probe2.csv',
        'fetch_correction': 'HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB)',
        'clock_note': 'GRBM_GUI_ACTIVE is summed over the 8 XCDs: clock = counter / 8 / kernel duration', 'layers': []}
 for L in LAYERS:

@@ -116,6 +116,19 @@ class GridState:
         return g
 
 
+def _dense_io(x):
+    """Reference-signature entry of the dense blocks (modules.py:63-95, 474-547 take and return [b, c, D, H, W]):
+    a cubic power-of-two grid goes to node rows (b * 8^depth + morton(x, y, z): the layout the whole net runs in) and
+    back.  Returns (rows, GridState, back(rows, depth) -> dense)."""
+    assert x.dim() == 5 and x.shape[2] == x.shape[3] == x.shape[4], 'dense blocks take cubic [b, c, S, S, S] grids'
+    S = x.shape[2]
+    depth = S.bit_length() - 1
+    assert 1 << depth == S, 'grid edge must be a power of two'
+    B = x.shape[0]
+    rows = ops.voxel2octree_cf(x.float().contiguous(), depth)
+    return rows, GridState(B, depth, x.device), (lambda r, d: ops.octree2voxel_cf(r, B, d))
+
+
 class GroupNorm32(nn.GroupNorm):
     """reference modules.py:26-28 (parameters ``weight`` / ``bias`` [C]); runs on libofx in row layout."""
 
@@ -190,7 +203,11 @@ class ConvUpsample(nn.Module):
         self.channels = channels
         self.conv = GridConv3d(channels, channels, mode=2)
 
-    def forward(self, x, gs, out=None):
+    def forward(self, x, gs=None, out=None):
+        """rows + GridState -> (rows, GridState one level finer); or the reference's ``forward(x)`` on [b, c, D, H, W]."""
+        if gs is None:
+            rows, gs, back = _dense_io(x)
+            return back(self.conv(rows, gs), gs.depth + 1)
         return self.conv(x, gs, out=out), gs.at(gs.depth + 1)
 
 
@@ -202,7 +219,11 @@ class ConvDownsample(nn.Module):
         self.channels = channels
         self.op = GridConv3d(channels, channels, mode=1)
 
-    def forward(self, x, gs):
+    def forward(self, x, gs=None):
+        """rows + GridState -> (rows, GridState one level coarser); or the reference's ``forward(x)`` on [b, c, D, H, W]."""
+        if gs is None:
+            rows, gs, back = _dense_io(x)
+            return back(self.op(rows, gs), gs.depth - 1)
         return self.op(x, gs), gs.at(gs.depth - 1)
 
 
@@ -221,8 +242,13 @@ class ResnetBlock(nn.Module):
         self.res_conv = _PointConv(dim_in, dim_out, 3) if dim_in != dim_out else nn.Identity()
 
     @torch.no_grad()
-    def forward(self, x, emb_act, gs, out=None):
-        """emb_act = SiLU(time embedding) [B, emb_dim] (shared by all blocks of a step)."""
+    def forward(self, x, emb_act, gs=None, out=None):
+        """Row layout: emb_act = SiLU(time embedding) [B, emb_dim] (shared by all blocks of a step).
+        Without ``gs``: the reference's ``forward(x, time_emb)`` (modules.py:505-513) on x [b, c, D, H, W] with the RAW
+        time embedding (time_mlp's SiLU is applied here)."""
+        if gs is None:
+            rows, gs, back = _dense_io(x)
+            return back(self.forward(rows, ops.act(emb_act.float().contiguous(), 'silu'), gs), gs.depth)
         h = self.block1[0](x, gs, act='silu')
         t = self.time_mlp[1](emb_act)                       # [B, dim_out]
         h = self.block1[2](h, gs, emb=t)                    # conv + bias + t[batch] fused
@@ -250,7 +276,11 @@ class AttentionBlock(nn.Module):
             p.detach().zero_()
 
     @torch.no_grad()
-    def forward(self, x, gs, out=None):
+    def forward(self, x, gs=None, out=None):
+        """rows + GridState; or the reference's ``forward(x)`` (modules.py:527-535) on [b, c, D, H, W]."""
+        if gs is None:
+            rows, gs, back = _dense_io(x)
+            return back(self.forward(rows, gs), gs.depth)
         qkv = self.qkv(self.norm(x, gs))
         h = ops.attention(qkv, gs.B, 8 ** gs.depth, self.num_heads)
         return self.proj_out(h, res=x, out=out)

@@ -495,7 +495,61 @@ def g_vae_train():
            'grads': grads}
     save('g_vae_train', rec)
 
+# ---------------------------------------------------------------- G12: the drop-in boundary at the REAL configs
+def g_boundary():
+    """What `load_ckpt(strict=True)` binds (octfusion_model_union.py:525-545, model_utils.py:18-28): the state_dict
+    key / shape lists, in order, of the reference's own nets built from its three diffusion YAMLs and its ShapeNet /
+    Objaverse VAE YAMLs -- plus the reference-signature dense blocks (modules.py:63-95, 474-547: [b, c, D, H, W] in
+    and out) on small inputs.  Keys and shapes go to a JSON file (readable diffs), tensors to g_boundary.pt."""
+    import json
+    from models.networks.dualoctree_networks.graph_vae import GraphVAE
+    cfg_dir = os.path.join(refenv.REF, 'configs')
+    rec = {}
+    for name, yaml_name, stage in (('snet_uncond', 'octfusion_snet_uncond.yaml', 'hr'),
+                                   ('snet_cond', 'octfusion_snet_cond.yaml', 'hr'),
+                                   ('obja_uncond', 'octfusion_obja_uncond.yaml', 'feature')):
+        cfg = refenv.load_yaml(os.path.join(cfg_dir, yaml_name))
+        params = dict(cfg['unet']['params'])
+        params.pop('df_type', None)
+        with torch.device('meta'):
+            net = RUnion(stage, **params)
+        rec[name] = {'yaml': yaml_name, 'stage_flag': stage,
+                     'keys': [[k, list(v.shape)] for k, v in net.state_dict().items()]}
+    for name, yaml_name in (('vae_snet', 'vae_snet_eval.yaml'), ('vae_obja_depth864', 'vae_obja_eval_depth864.yaml')):
+        m = refenv.load_yaml(os.path.join(cfg_dir, yaml_name))['model']
+        with torch.device('meta'):
+            vae = GraphVAE(depth=m['depth'], channel_in=m['channel'], nout=m['nout'], full_depth=m['full_depth'],
+                           depth_stop=m['depth_stop'], depth_out=m['depth_out'], use_checkpoint=False,
+                           resblk_type=m['resblock_type'], bottleneck=m['bottleneck'], resblk_num=m['resblk_num'],
+                           code_channel=m['code_channel'], embed_dim=m['embed_dim'])
+        rec[name] = {'yaml': yaml_name, 'model': {k: m[k] for k in ('depth', 'channel', 'nout', 'full_depth', 'depth_stop',
+                                                                    'depth_out', 'resblock_type', 'bottleneck',
+                                                                    'resblk_num', 'code_channel', 'embed_dim')},
+                     'keys': [[k, list(v.shape)] for k, v in vae.state_dict().items()]}
+    with open(os.path.join(HERE, 'boundary_keys.json'), 'w') as f:
+        json.dump(rec, f, indent=0)
+    print('%-28s %8.1f KB' % ('boundary_keys.json', os.path.getsize(os.path.join(HERE, 'boundary_keys.json')) / 1024))
+    # dense blocks through their reference signatures
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    m = RM.ConvDownsample(16, dims=3)
+    ks = load_filled(m)
+    x = torch.randn(2, 16, 8, 8, 8, generator=g)
+    out['convdown'] = {'x': x, 'keys': ks, 'out': m(x)}
+    m = RM.ConvUpsample(16, dims=3)
+    ks = load_filled(m)
+    x = torch.randn(2, 16, 4, 4, 4, generator=g)
+    out['convup'] = {'x': x, 'keys': ks, 'out': m(x)}
+    m = RM.ResnetBlock(3, 32, 32, emb_dim=16, dropout=0.0, use_text_condition=False)
+    ks = load_filled(m)
+    x = torch.randn(2, 32, 8, 8, 8, generator=g)
+    emb = torch.randn(2, 16, generator=g)
+    out['resnet_same'] = {'x': x, 'emb': emb, 'keys': ks, 'out': m(x, emb)}
+    save('g_boundary', out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['octree_graph', 'modules', 'dense', 'unet', 'sample_loop', 'vae', 'mpu', 'vae_enc', 'vae_train']
+    which = sys.argv[1:] or ['octree_graph', 'modules', 'dense', 'unet', 'sample_loop', 'vae', 'mpu', 'vae_enc', 'vae_train',
+                             'boundary']
     for w in which:
         globals()['g_' + w]()

@@ -93,3 +93,36 @@ def test_planes_kernels_have_no_scratch():
         res = list(ex.map(audit, ['ofx_gemm3.hip', 'ofx_gemm2.hip']))
     assert res[0][0] == 8 and res[1][0] == 8, res          # 2 precisions x 2 geometries x 2 tile widths each
     assert not res[0][1] and not res[1][1], res
+
+
+def test_state_dict_boundary_at_the_real_configs():
+    """The drop-in boundary: `load_ckpt(strict=True)` (octfusion_model_union.py:525-545) binds the
+    state_dict keys of the reference's nets.  tests/golden/boundary_keys.json holds the (key, shape) lists, in order,
+    of the reference's OWN UNet3DModel built from its three diffusion YAMLs and of its GraphVAE built from the two VAE
+    YAMLs (tests/golden/make_golden.py g_boundary); the product's modules must give the same lists."""
+    import json
+    import torch
+    from octfusion_amd import configs
+    from octfusion_amd.graph_unet_union import UNet3DModel
+    from octfusion_amd.graph_vae import GraphVAE
+    want = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'boundary_keys.json')))
+    sizes = {}
+    for name in ('snet_uncond', 'snet_cond', 'obja_uncond'):
+        rec = want[name]
+        with torch.device('meta'):
+            net = UNet3DModel(**configs.unet_params(name, rec['stage_flag']))
+        have = [[k, list(v.shape)] for k, v in net.state_dict().items()]
+        assert have == rec['keys'], name
+        sizes[name] = len(have)
+    assert sizes == {'snet_uncond': 232, 'snet_cond': 312, 'obja_uncond': 379}
+    for name, cfg in (('vae_snet', 'snet_uncond'), ('vae_obja_depth864', 'obja_uncond')):
+        rec = want[name]
+        kw = configs.vae_params(cfg)
+        m = rec['model']          # the YAML's own numbers against the restated config
+        assert (kw['depth'], kw['channel_in'], kw['nout'], kw['full_depth'], kw['depth_stop'], kw['depth_out'],
+                kw['resblk_type'], kw['resblk_num'], kw['code_channel'], kw['embed_dim']) == (
+            m['depth'], m['channel'], m['nout'], m['full_depth'], m['depth_stop'], m['depth_out'], m['resblock_type'],
+            m['resblk_num'], m['code_channel'], m['embed_dim'])
+        with torch.device('meta'):
+            vae = GraphVAE(**kw)
+        assert [[k, list(v.shape)] for k, v in vae.state_dict().items()] == rec['keys'], name

@@ -141,6 +141,78 @@ def test_full_width_lr_step():
         assert e['rel_to_max'] < bound, (prec, planes, e)
 
 
+def test_full_width_hr_step_batch8():
+    """The bench's own workload size: configs[2], one whole hr step (+ nested lr) on the jittered shell-6 batch of
+    EIGHT shapes (N = 217 008) against the oracle, default precision mode (graph_unet_hr.py:214-281)."""
+    from octfusion_amd import configs, synthetic
+    from octfusion_amd.graph_unet_union import UNet3DModel
+    from oracle import modules as OM, sampler as OS, unet as OU
+    B = 8
+    oc, doc, o_oc, o_doc = shell6(B)
+    assert doc.total_num == 217008
+    net = UNet3DModel(**configs.unet_params('snet_uncond', 'hr'))
+    sd = synthetic.random_state_dict(net)
+    net.load_state_dict(sd)
+    net = net.to(dev()).eval()
+    st = configs.stage_cfgs('snet_uncond')
+    x = C.rand_input('fw_b8', doc.total_num, 3)
+    log_snr = OS.beta_linear_log_snr(torch.full((B,), 0.6))
+    t0 = time.time()
+    parts = {p: OM._sub(sd, p) for p in ('unet_lr', 'unet_hr')}
+    ref = OU.hr_forward(parts['unet_hr'], st['hr'], x, o_doc, log_snr, None, parts['unet_lr'], st['lr'])
+    t_or = time.time() - t0
+    y = net(unet_type='hr', x=x.to(dev()), doctree=doc, unet_lr=net.unet_lr, timesteps=log_snr.to(dev()),
+            x_self_cond=None, label=None)
+    e = errors(y, ref)
+    report(dict(test='hr_step_b8', config='snet_uncond', B=B, N=doc.total_num, precision='default', oracle_s=t_or, **e))
+    assert e['rel_to_max'] < 1e-3, e
+    from octfusion_amd import ops
+    assert not ops.sync_error(dev())
+
+
+def test_full_width_obja_hr_and_cond_lr_steps():
+    """The two stand-alone stages the nested runs do not cover at full width: the Objaverse hr stage (8-channel split
+    codes in and out, x0 prediction, num_res_blocks [2, 2, 0]; configs/octfusion_obja_uncond.yaml:11-19) with its lr net
+    nested, and the conditional ShapeNet lr stage (channel_mult [1, 2, 4, 8]: a 2^3 level with attention, 5 classes;
+    configs/octfusion_snet_cond.yaml:19-25)."""
+    from octfusion_amd import configs, synthetic
+    from octfusion_amd.graph_unet_union import UNet3DModel
+    from oracle import modules as OM, sampler as OS, unet as OU
+    B = 2
+    oc, doc, o_oc, o_doc = shell6(B)
+    net = UNet3DModel(**configs.unet_params('obja_uncond', 'hr'))
+    sd = synthetic.random_state_dict(net)
+    net.load_state_dict(sd)
+    net = net.to(dev()).eval()
+    st = configs.stage_cfgs('obja_uncond')
+    x = C.rand_input('fw_obja_hr', doc.total_num, 8)
+    log_snr = OS.beta_linear_log_snr(torch.full((B,), 0.35))
+    parts = {p: OM._sub(sd, p) for p in ('unet_lr', 'unet_hr')}
+    ref = OU.hr_forward(parts['unet_hr'], st['hr'], x, o_doc, log_snr, None, parts['unet_lr'], st['lr'])
+    assert ref.shape == (doc.total_num, 8)
+    y = net(unet_type='hr', x=x.to(dev()), doctree=doc, unet_lr=net.unet_lr, timesteps=log_snr.to(dev()),
+            x_self_cond=None, label=None)
+    e = errors(y, ref)
+    report(dict(test='obja_hr_step', B=B, N=doc.total_num, precision='default', **e))
+    assert e['rel_to_max'] < 1e-3, e
+
+    Bl = 4
+    net = UNet3DModel(**configs.unet_params('snet_cond', 'lr'))
+    sd = synthetic.random_state_dict(net)
+    net.load_state_dict(sd)
+    net = net.to(dev()).eval()
+    st = configs.stage_cfgs('snet_cond')
+    xl = C.rand_input('fw_cond_lr', Bl, 8, 16, 16, 16)
+    xsc = C.rand_input('fw_cond_lr_sc', Bl, 8, 16, 16, 16)
+    ls = OS.beta_linear_log_snr(torch.full((Bl,), 0.8))
+    label = torch.arange(Bl) % 5
+    ref = OU.lr_forward(OM._sub(sd, 'unet_lr'), st['lr'], xl, ls, xsc, label)
+    y = net(unet_type='lr', x=xl.to(dev()), timesteps=ls.to(dev()), x_self_cond=xsc.to(dev()), label=label.to(dev()))
+    e = errors(y, ref)
+    report(dict(test='cond_lr_step', B=Bl, precision='default', **e))
+    assert e['rel_to_max'] < 1e-3, e
+
+
 def test_full_width_feature_step():
     """configs[4]: obja 3-stage -- the feature net on a shell-8 tree (N8 = 448 232) with the hr net nested as its
     middle (run as_middle, itself without the lr net): octfusion_model_union_3t.py:152-214, graph_unet_hr.py:211-281."""

@@ -770,6 +770,32 @@ def test_precision_modes_vs_oracle():
     assert e16 < 5e-5, e16
 
 
+def test_dense_blocks_reference_signatures(golden):
+    """ResnetBlock.forward(x, time_emb), AttentionBlock.forward(x), ConvDownsample / ConvUpsample.forward(x)
+    on [b, c, D, H, W] tensors (modules.py:63-95, 474-547) -- called exactly the way the reference calls them, against
+    the reference's own outputs (g_dense: attn / attn512 / resnet; g_boundary: convdown / convup / resnet_same)."""
+    from octfusion_amd import graph_unet_lr as LR
+    G, Gb = golden('g_dense'), golden('g_boundary')
+    m = load(LR.AttentionBlock(32, num_heads=4), G['attn']['keys'])
+    y = m(G['attn']['x'].to(dev()))
+    assert y.shape == G['attn']['out'].shape
+    close(y, G['attn']['out'])
+    m = load(LR.AttentionBlock(128, num_heads=4), G['attn512']['keys'])
+    close(m(G['attn512']['x'].to(dev())), G['attn512']['out'])
+    m = load(LR.ResnetBlock(3, 8, 12, emb_dim=16, dropout=0.0), G['resnet']['keys'])
+    close(m(G['resnet']['x'].to(dev()), G['resnet']['emb'].to(dev())), G['resnet']['out'])
+    m = load(LR.ResnetBlock(3, 32, 32, emb_dim=16, dropout=0.0), Gb['resnet_same']['keys'])
+    close(m(Gb['resnet_same']['x'].to(dev()), Gb['resnet_same']['emb'].to(dev())), Gb['resnet_same']['out'])
+    m = load(LR.ConvDownsample(16, dims=3), Gb['convdown']['keys'])
+    y = m(Gb['convdown']['x'].to(dev()))
+    assert tuple(y.shape) == (2, 16, 4, 4, 4)
+    close(y, Gb['convdown']['out'])
+    m = load(LR.ConvUpsample(16, dims=3), Gb['convup']['keys'])
+    y = m(Gb['convup']['x'].to(dev()))
+    assert tuple(y.shape) == (2, 16, 8, 8, 8)
+    close(y, Gb['convup']['out'])
+
+
 def test_dense_and_unet(golden):
     from octfusion_amd import graph_unet_lr as LR, graph_unet_union as U, ops
     G = golden('g_dense')

@@ -1,0 +1,121 @@
+"""The precision contract, with data.
+
+north_star's bar is 1e-3 relative fp32 against the reference path.  Two figures per whole denoising step at the real
+widths (tests/test_gpu_fullwidth.errors): rel-to-max, and the ELEMENT-WISE error |a-b| / max(|b|, 1 % of max|b|) at
+its 99.9th percentile.  The reference's own fp32 arithmetic is not exact either: tools/oracle_noise.py runs the oracle
+in float32 and in float64 on the same inputs (profiles/r03/oracle_fp32_noise.json: element-wise p99.9 2.0e-4 on an hr
+step, 5.9e-4 on an lr step), so errors are taken against the float64 run of the oracle -- the reference's op sequence
+without its rounding noise -- and the float32 run is measured beside the product.
+
+Default mode = bf16x3 on the wide GraphConvs, exact fp32 for the dense lr net and the <= 64-channel layers
+(ops.POLICY).  Asserted here:
+  * hr / lr step, default mode: element-wise p99.9 <= 1e-3 AND rel-to-max <= 1e-4;
+  * the default mode is within 6x of the reference's own fp32 noise on the element-wise figure;
+  * 50 DDIM steps: the distance between the default mode and exact fp32 stays below the distance between exact fp32
+    and the CPU oracle on the same noises (the nets are chaotic: every pair drifts apart; the contraction precision
+    must not be what sets the drift).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+import common as C
+from test_gpu_fullwidth import dev, errors, report, shell6
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _dbl(parts):
+    return {k: {kk: (vv.double() if vv.is_floating_point() else vv) for kk, vv in v.items()} for k, v in parts.items()}
+
+
+def test_elementwise_contract_hr_and_lr_steps():
+    from octfusion_amd import configs, ops, synthetic
+    from octfusion_amd.graph_unet_union import UNet3DModel
+    from oracle import modules as OM, sampler as OS, unet as OU
+    B = 2
+    oc, doc, o_oc, o_doc = shell6(B)
+    net = UNet3DModel(**configs.unet_params('snet_uncond', 'hr'))
+    sd = synthetic.random_state_dict(net)
+    net.load_state_dict(sd)
+    net = net.to(dev()).eval()
+    st = configs.stage_cfgs('snet_uncond')
+    parts = {p: OM._sub(sd, p) for p in ('unet_lr', 'unet_hr')}
+    p64 = _dbl(parts)
+    x = C.rand_input('fw_snet_uncond', doc.total_num, 3)
+    log_snr = OS.beta_linear_log_snr(torch.full((B,), 0.6))
+    r32 = OU.hr_forward(parts['unet_hr'], st['hr'], x, o_doc, log_snr, None, parts['unet_lr'], st['lr'])
+    with OM.working_float(torch.float64):
+        r64 = OU.hr_forward(p64['unet_hr'], st['hr'], x.double(), o_doc, log_snr.double(), None, p64['unet_lr'], st['lr'])
+    Bl = 4
+    xl = C.rand_input('fw_lr', Bl, 8, 16, 16, 16)
+    xsc = C.rand_input('fw_lr_sc', Bl, 8, 16, 16, 16)
+    ls = OS.beta_linear_log_snr(torch.full((Bl,), 0.3))
+    l32 = OU.lr_forward(parts['unet_lr'], st['lr'], xl, ls, xsc, None)
+    with OM.working_float(torch.float64):
+        l64 = OU.lr_forward(p64['unet_lr'], st['lr'], xl.double(), ls.double(), xsc.double(), None)
+    assert ops.get_precision() == 'bf16x3' and ops.POLICY == {'dense_net': 'fp32', 'small_gemm': 'fp32'}
+    cases = [('hr', lambda: net(unet_type='hr', x=x.to(dev()), doctree=doc, unet_lr=net.unet_lr,
+                                timesteps=log_snr.to(dev()), x_self_cond=None, label=None), r32, r64),
+             ('lr', lambda: net(unet_type='lr', x=xl.to(dev()), timesteps=ls.to(dev()), x_self_cond=xsc.to(dev())), l32, l64)]
+    for step, run, ref32, ref64 in cases:
+        floor = errors(ref32, ref64)                       # the reference's own fp32 rounding noise
+        e = errors(run(), ref64)
+        ops.set_precision('fp32')
+        try:
+            e32 = errors(run(), ref64)
+        finally:
+            ops.set_precision('bf16x3')
+        report(dict(test='precision_contract', step=step, default=e, exact_fp32=e32, reference_fp32_noise=floor))
+        assert e['elementwise_p999'] <= 1e-3, (step, e)
+        assert e['rel_to_max'] <= 1e-4, (step, e)
+        assert e['elementwise_p999'] <= 6 * max(floor['elementwise_p999'], e32['elementwise_p999']), (step, e, floor, e32)
+
+
+def test_ddim_drift_50_steps():
+    """50 eps-branch DDIM steps of the hr net (+ nested lr) on one shell-6 shape at the real widths, the same initial
+    noise everywhere: default mode vs exact fp32 (both on the GPU) vs the CPU oracle."""
+    from octfusion_amd import configs, ops, sampler, synthetic
+    from octfusion_amd.dual_octree import DualOctree
+    from octfusion_amd.graph_unet_union import UNet3DModel
+    from octfusion_amd.octree import split2octree_small
+    from oracle import dual_octree as OD, modules as OM, sampler as OS, unet as OU
+    steps, B = 50, 1
+    split = synthetic.shell6_split(B, jitter=False)
+    doc = DualOctree(split2octree_small(split.to(dev()), 6, 4))
+    o_doc = OD.OracleDualOctree(OS.split2octree_small(split, 6, 4))
+    o_doc.post_processing_for_docnn()
+    net = UNet3DModel(**configs.unet_params('snet_uncond', 'hr'))
+    sd = synthetic.random_state_dict(net)
+    net.load_state_dict(sd)
+    net = net.to(dev()).eval()
+    st = configs.stage_cfgs('snet_uncond')
+    parts = {p: OM._sub(sd, p) for p in ('unet_lr', 'unet_hr')}
+    init = C.rand_input('drift_init', doc.total_num, 3)
+
+    def gpu_run():
+        return sampler.sample_loop(net, tuple(init.shape), B, steps, 'hr', 'eps', dev(), doctree=doc, unet_lr=net.unet_lr,
+                                   init_noise=init).cpu()
+    x_def = gpu_run()
+    ops.set_precision('fp32')
+    try:
+        x_f32 = gpu_run()
+    finally:
+        ops.set_precision('bf16x3')
+    x_or = OS.sample_loop(lambda x, ls, xs: OU.hr_forward(parts['unet_hr'], st['hr'], x, o_doc, ls, None, parts['unet_lr'],
+                                                           st['lr']),
+                          tuple(init.shape), B, steps, 'hr', 'eps', init_noise=init)
+    nrm = float(x_or.norm())
+    d_prec = float((x_def - x_f32).norm()) / nrm
+    d_impl = float((x_f32 - x_or).norm()) / nrm
+    d_def = float((x_def - x_or).norm()) / nrm
+    report(dict(test='ddim_drift', steps=steps, N=doc.total_num, default_vs_fp32=d_prec, fp32_vs_oracle=d_impl,
+                default_vs_oracle=d_def))
+    assert all(torch.isfinite(t).all() for t in (x_def, x_f32, x_or))
+    # the contraction precision must not be what sets the drift: the default mode sits as close to the oracle as
+    # exact fp32 does (within 25 %), and no further from exact fp32 than exact fp32 is from the oracle (x2 margin)
+    assert d_def <= 1.25 * d_impl + 1e-6, (d_def, d_impl)
+    assert d_prec <= 2.0 * d_impl + 1e-6, (d_prec, d_impl)

@@ -189,6 +189,23 @@ def test_dense(golden):
                                m['out'], **TOL)
 
 
+def test_dense_boundary_blocks(golden):
+    """g_boundary: the reference's ConvDownsample / ConvUpsample / same-width ResnetBlock on dense tensors
+    (modules.py:63-95, 474-513) -- the oracle's restatements of them (conv3d stride 2; nearest x2 + conv3d;
+    resnet_block with an identity skip) against the reference's outputs."""
+    import torch.nn.functional as F
+    G = golden('g_boundary')
+    r = G['convdown']
+    sd = C.fill_state_dict(r['keys'])
+    torch.testing.assert_close(F.conv3d(r['x'], sd['op.weight'], sd['op.bias'], stride=2, padding=1), r['out'], **TOL)
+    r = G['convup']
+    sd = C.fill_state_dict(r['keys'])
+    torch.testing.assert_close(F.conv3d(F.interpolate(r['x'], scale_factor=2, mode='nearest'), sd['conv.weight'],
+                                        sd['conv.bias'], padding=1), r['out'], **TOL)
+    r = G['resnet_same']
+    torch.testing.assert_close(OM.resnet_block(r['x'], r['emb'], C.fill_state_dict(r['keys'])), r['out'], **TOL)
+
+
 def split_union_sd(sd):
     return {p: OM._sub(sd, p) for p in ('unet_lr', 'unet_hr', 'unet_feature')}
 

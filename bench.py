@@ -5,7 +5,8 @@ Default workload = BASELINE.json configs[2], the one `metric` is quoted on: Shap
 (configs/octfusion_snet_uncond.yaml) on the synthetic shell-6 octree batch (diffusion depth 6 of the
 depth-8 VAE octree), batch 8 per GPU, DDIM eps-branch.  One step = one full U-Net forward (sparse hr net + the
 nested dense lr net) + the DDIM update for the whole batch.  Inputs are resident in HBM before the timed region.
-fp32 storage; default contraction bf16x3 (fp32-class, ~6e-5 through the net), exact fp32 MFMA timed beside it.
+fp32 storage; default contraction fp16x3 (fp16 hi/lo operand pairs, three fp16 MFMAs per product, fp32 accumulate:
+the fp32 reference's rounding class); exact fp32 MFMA and the bf16-pair variant are timed beside it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hr|lr|hr_cond|feature]
 
@@ -30,6 +31,9 @@ if ROOT not in sys.path:
 MFMA_F32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
 MFMA_16BIT_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA (no 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec peak
+# matrix roof of the ALGORITHMIC flops per contraction mode: the three-term modes issue 3 MFMAs per product
+PEAKS = {'fp16x3': MFMA_16BIT_PEAK_TFLOPS / 3.0, 'bf16x3': MFMA_16BIT_PEAK_TFLOPS / 3.0, 'fp32': MFMA_F32_PEAK_TFLOPS,
+         'fp16': MFMA_16BIT_PEAK_TFLOPS}
 
 # BASELINE.json configs -> concrete synthetic inputs
 WORKLOADS = {
@@ -319,7 +323,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='hr', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='shapes per GPU (weak scaling)')
-    ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'fp32', 'fp16'])
+    ap.add_argument('--precision', default='fp16x3', choices=['fp16x3', 'bf16x3', 'fp32', 'fp16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='time eager launches instead of hipGraph replay')
     ap.add_argument('--no-extras', action='store_true', help='skip the fp32 / old-kernel / graph / sustained side runs')
@@ -446,12 +450,12 @@ def main():
     res = None
     if rank == 0:
         bf = args.precision
-        peak = {'bf16x3': MFMA_16BIT_PEAK_TFLOPS / 3.0, 'fp32': MFMA_F32_PEAK_TFLOPS, 'fp16': MFMA_16BIT_PEAK_TFLOPS}[bf]
-        planes_kind = {'bf16x3': 'graph2', 'fp16': 'graph2h'}.get(bf)
+        peak = PEAKS[bf]
+        planes_kind = {'fp16x3': 'graph2', 'bf16x3': 'graph2', 'fp16': 'graph2h'}.get(bf)
         dom = profile_summary(prof, dt_prof, (planes_kind,), peak) if planes_kind else None
         dom_name = ('gconv3_kernel<%d,*,*> (fused GraphConv on operand planes, persistent stream-K blocks: LDS-DMA gather '
                     '-> %s MFMA, fp32 accumulate; gconv2_kernel for the layers too small for it)'
-                    % ((2, 'bf16x3') if bf == 'bf16x3' else (1, 'fp16')))
+                    % {'fp16x3': (3, 'fp16x3 (three fp16 MFMAs per product)'), 'bf16x3': (2, 'bf16x3'), 'fp16': (1, 'fp16')}[bf])
         if dom is None:         # exact-fp32 mode / dense lr stage: the register-staged kernel carries the time
             dom = profile_summary(prof, dt_prof, ('graph', 'grid'), peak)
             dom_name = 'gemm_fast_kernel / gemm_bf16x3_kernel<MODE_GATHER> (register-staged fused GraphConv / 27-tap gridconv)'
@@ -502,7 +506,9 @@ def main():
             'metric': 'denoising-steps/sec (depth-8 octree, batch 8)', 'value': world * K / dt,
             'unit': 'steps/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': ms_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'bf16x3': 'f32 storage, bf16x3 products (16-bit significand pairs, fp32 accumulate)',
+            'dtype': {'fp16x3': 'f32 storage, fp16x3 products (fp16 hi + lo operand pairs = 22 significand bits, three fp16 '
+                                'MFMAs per product, fp32 accumulate)',
+                      'bf16x3': 'f32 storage, bf16x3 products (16-bit significand pairs, fp32 accumulate)',
                       'fp32': 'f32', 'fp16': 'f32 storage, fp16 products in GraphConv (reduced precision)'}[bf],
             'contraction': bf, 'data': 'synthetic',
             'execution': 'hipGraph replay of the captured step' if replay is not None else 'eager launches',
@@ -542,7 +548,7 @@ def main():
             ops.GRAPHCONV_PROFILE = p2
             t = timed(lambda: wl.run(2, n_side))
             ops.GRAPHCONV_PROFILE = None
-            pk = {'bf16x3': MFMA_16BIT_PEAK_TFLOPS / 3.0, 'fp32': MFMA_F32_PEAK_TFLOPS, 'fp16': MFMA_16BIT_PEAK_TFLOPS}[precision]
+            pk = PEAKS[precision]
             s = profile_summary(p2, t, ('graph', 'graph2', 'graph2h'), pk)
             extras[label] = {'ms_per_step': 1e3 * t / n_side, 'steps': n_side,
                              'graphconv_TFLOPs': s and s['algorithmic_TFLOPs'], 'graphconv_mfma_frac': s and s['mfma_frac'],
@@ -557,8 +563,9 @@ def main():
                                           'achieved': extras['fp32_exact']['graphconv_TFLOPs'],
                                           'frac': extras['fp32_exact']['graphconv_mfma_frac'],
                                           'kernel': 'gemm_fast_kernel<MODE_GATHER> (exact fp32 MFMA, register-staged)'}
-            if args.precision == 'bf16x3' and wl.doc is not None:
-                side('bf16x3_register_staged_kernel', 'bf16x3', False)
+            if args.precision == 'fp16x3' and wl.doc is not None:
+                side('bf16x3', 'bf16x3', True)
+                side('fp16x3_register_staged_kernel', 'fp16x3', False)
                 side('fp16_single_pass', 'fp16', True)
         finally:
             ops.set_precision(args.precision)

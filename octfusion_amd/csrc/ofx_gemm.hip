@@ -531,6 +531,8 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(const GemmArgs g) {
 // pre-split once by the pack kernels.  LDS per buffer: A_hi/A_lo [128][32+8] bf16 (80-B rows:
 // conflict-free b128 reads), B_hi/B_lo [4][BN][8] bf16.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8h_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4h __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
   unsigned r;
@@ -545,8 +547,37 @@ __device__ __forceinline__ void split_bf16x4(const float4& v, uint2& hi, uint2& 
   lo.x = cvt_pk_bf16(v.x - hx, v.y - hy);
   lo.y = cvt_pk_bf16(v.z - hz, v.w - hw);
 }
+// H16 = 0: bf16 pairs ("bf16x3"); 1: fp16 pairs ("fp16x3": 11 + 11 significand bits, same three MFMAs per product --
+// v_mfma_f32_32x32x16_f16 honours fp16 denormals, so the lo part stays exact down to 2^-24; values saturate at the
+// fp16 range).  See ofx_planes.h for the formats.
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+  const _Float16 x = (_Float16)a, y = (_Float16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ float f16_lo_f32(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
+__device__ __forceinline__ float f16_hi_f32(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
+__device__ __forceinline__ float sat_f16(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
+template <int H16>
+__device__ __forceinline__ void split16x4(const float4& v, uint2& hi, uint2& lo) {
+  if constexpr (H16 == 0) {
+    split_bf16x4(v, hi, lo);
+  } else {
+    const float x = sat_f16(v.x), y = sat_f16(v.y), z = sat_f16(v.z), w = sat_f16(v.w);
+    hi.x = cvt_pk_f16(x, y);
+    hi.y = cvt_pk_f16(z, w);
+    lo.x = cvt_pk_f16(x - f16_lo_f32(hi.x), y - f16_hi_f32(hi.x));
+    lo.y = cvt_pk_f16(z - f16_lo_f32(hi.y), w - f16_hi_f32(hi.y));
+  }
+}
+template <int H16>
+__device__ __forceinline__ f32x16 mfma16(u32x4h a, u32x4h b, f32x16 c) {
+  if constexpr (H16 == 0)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8h_t, a), __builtin_bit_cast(f16x8h_t, b), c, 0, 0, 0);
+}
 
-template <int MODE, int WM, int WN, int MI, int NI>
+template <int MODE, int WM, int WN, int MI, int NI, int H16>
 __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
   // LDS carries only the A tile (hi and lo planes, [128][32+8] bf16 each, double buffered = 40 KB).
   // The weight fragments go global(L2) -> registers directly in MFMA operand layout (the packed
@@ -650,24 +681,24 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
   auto store_a = [&](int buf, const RegSet& R) {
     char* a = a_st + buf * BUF_BYTES;
     uint2 hi, lo;
-    split_bf16x4(R.a0, hi, lo);
+    split16x4<H16>(R.a0, hi, lo);
     *reinterpret_cast<uint2*>(a) = hi; *reinterpret_cast<uint2*>(a + A_BYTES) = lo;
-    split_bf16x4(R.a1, hi, lo);
+    split16x4<H16>(R.a1, hi, lo);
     *reinterpret_cast<uint2*>(a + 32 * 80) = hi; *reinterpret_cast<uint2*>(a + 32 * 80 + A_BYTES) = lo;
-    split_bf16x4(R.a2, hi, lo);
+    split16x4<H16>(R.a2, hi, lo);
     *reinterpret_cast<uint2*>(a + 64 * 80) = hi; *reinterpret_cast<uint2*>(a + 64 * 80 + A_BYTES) = lo;
-    split_bf16x4(R.a3, hi, lo);
+    split16x4<H16>(R.a3, hi, lo);
     *reinterpret_cast<uint2*>(a + 96 * 80) = hi; *reinterpret_cast<uint2*>(a + 96 * 80 + A_BYTES) = lo;
   };
   auto compute = [&](int buf, const BFrag& F) {
     const char* a = a_ld + buf * BUF_BYTES;
-    bf16x8_t ah[2][MI], al[2][MI];
+    u32x4h ah[2][MI], al[2][MI];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        ah[c][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + 32 * c);
-        al[c][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + 32 * c + A_BYTES);
+        ah[c][i] = *reinterpret_cast<const u32x4h*>(a + i * 32 * 80 + 32 * c);
+        al[c][i] = *reinterpret_cast<const u32x4h*>(a + i * 32 * 80 + 32 * c + A_BYTES);
       }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -675,17 +706,17 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[c][i], __builtin_bit_cast(bf16x8_t, F.h[c][j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<H16>(al[c][i], F.h[c][j], acc[i][j]);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c][i], __builtin_bit_cast(bf16x8_t, F.l[c][j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<H16>(ah[c][i], F.l[c][j], acc[i][j]);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c][i], __builtin_bit_cast(bf16x8_t, F.h[c][j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<H16>(ah[c][i], F.h[c][j], acc[i][j]);
     }
   };
 
@@ -731,9 +762,9 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
     auto store_half = [&](int buf, const float4& v0, const float4& v1, int row_off) {
       char* a = a_st + buf * BUF_BYTES + row_off * 80;
       uint2 hi, lo;
-      split_bf16x4(v0, hi, lo);
+      split16x4<H16>(v0, hi, lo);
       *reinterpret_cast<uint2*>(a) = hi; *reinterpret_cast<uint2*>(a + A_BYTES) = lo;
-      split_bf16x4(v1, hi, lo);
+      split16x4<H16>(v1, hi, lo);
       *reinterpret_cast<uint2*>(a + 32 * 80) = hi; *reinterpret_cast<uint2*>(a + 32 * 80 + A_BYTES) = lo;
     };
 #define OFX_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -748,20 +779,20 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
                     RegSet& Rnew, const RegSet& Rold) {
       const char* a = a_ld + buf * BUF_BYTES;
       const int ktw = ktw_of(it + 1);
-      bf16x8_t ah[2][MI], al[2][MI];
+      u32x4h ah[2][MI], al[2][MI];
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-          ah[c][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + 32 * c);
-          al[c][i] = *reinterpret_cast<const bf16x8_t*>(a + i * 32 * 80 + 32 * c + A_BYTES);
+          ah[c][i] = *reinterpret_cast<const u32x4h*>(a + i * 32 * 80 + 32 * c);
+          al[c][i] = *reinterpret_cast<const u32x4h*>(a + i * 32 * 80 + 32 * c + A_BYTES);
         }
       load_idx(it + 3, Iload);
       OFX_FENCE();
 #define OFX_MFMA_GROUP(AOP, BOP, C)                                                                        \
       _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                        \
         _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                      \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AOP[C][i], __builtin_bit_cast(bf16x8_t, Fcur.BOP[C][j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<H16>(AOP[C][i], Fcur.BOP[C][j], acc[i][j]);
       OFX_MFMA_GROUP(al, h, 0);
       OFX_FENCE();
       load_bchunk(ktw, 0, Fnext);
@@ -837,7 +868,8 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {
   const uint32_t u = __float_as_uint(f);
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-__global__ void pack_bf16x3_kernel(const float* __restrict__ Wp, int64_t Kp, int64_t N, uint16_t* __restrict__ W16) {
+__global__ void pack_bf16x3_kernel(const float* __restrict__ Wp, int64_t Kp, int64_t N, uint16_t* __restrict__ W16,
+                                   int h16) {
   const int64_t total = Kp * N;            // one element per (k, n)
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t kg = t / (N * 8), rem = t - kg * N * 8;
@@ -845,23 +877,37 @@ __global__ void pack_bf16x3_kernel(const float* __restrict__ Wp, int64_t Kp, int
     const int kk = (int)(rem - n * 8);
     const int64_t k = kg * 8 + kk;
     const float w = Wp[((k >> 2) * N + n) * 4 + (k & 3)];
-    const uint32_t hi = bf16_rne_bits(w);
-    const float wl = w - __uint_as_float(hi << 16);
-    W16[t] = (uint16_t)hi;
-    W16[total + t] = (uint16_t)bf16_rne_bits(wl);
+    if (h16) {                             // fp16 pairs (precision 3)
+      const float ws = sat_f16(w);
+      const _Float16 hi = (_Float16)ws;
+      const _Float16 lo = (_Float16)(ws - (float)hi);
+      W16[t] = __builtin_bit_cast(unsigned short, hi);
+      W16[total + t] = __builtin_bit_cast(unsigned short, lo);
+    } else {
+      const uint32_t hi = bf16_rne_bits(w);
+      const float wl = w - __uint_as_float(hi << 16);
+      W16[t] = (uint16_t)hi;
+      W16[total + t] = (uint16_t)bf16_rne_bits(wl);
+    }
   }
 }
+static int g_precision = 3;
+// the 16-bit planes behind the fp32 pack follow the precision that is set WHEN THE WEIGHTS ARE PACKED (bf16 pairs for
+// precisions 0 / 2, fp16 pairs for 3; unused by 1): the Python cache keys its packs on the precision, C callers re-pack
+// after ofx_set_precision
 static int pack_bf16x3(const float* Wp, int64_t Kp, int64_t N, hipStream_t st) {
   uint16_t* W16 = reinterpret_cast<uint16_t*>(const_cast<float*>(Wp) + Kp * N);
-  pack_bf16x3_kernel<<<ofx_grid(Kp * N, 256), 256, 0, st>>>(Wp, Kp, N, W16);
+  pack_bf16x3_kernel<<<ofx_grid(Kp * N, 256), 256, 0, st>>>(Wp, Kp, N, W16, g_precision == 3 ? 1 : 0);
   return OFX_OK;
 }
 
-// 0: bf16x3 on the bf16 matrix pipe (default), 1: exact fp32 MFMA, 2: fp16 single pass in the planes GraphConv
-// (ofx_gemm2.hip), bf16x3 here.  Process-wide and unsynchronised: set it from the launching thread between launches.
-static int g_precision = 0;
+// 3 (default): fp16x3 -- operands as fp16 hi + lo pairs, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate:
+//    ~2^-21 per product (the fp32 reference's own rounding class) at the cost of bf16x3;
+// 0: bf16x3 -- the same with bf16 pairs (2^-16 per product; round 1 / 2's default); 1: exact fp32 MFMA;
+// 2: fp16 single pass in the planes GraphConv (ofx_gemm2.hip / ofx_gemm3.hip), bf16x3 here.
+// Process-wide and unsynchronised: set it from the launching thread between launches.
 extern "C" int ofx_set_precision(int mode) {
-  if (mode < 0 || mode > 2) return OFX_EINVAL;
+  if (mode < 0 || mode > 3) return OFX_EINVAL;
   g_precision = mode;
   return OFX_OK;
 }
@@ -966,16 +1012,20 @@ static int launch_fast_cfg(GemmArgs& g, hipStream_t st) {
   return OFX_OK;
 }
 
-template <int MODE, int WM, int WN, int MI, int NI>
-static int launch_bf16x3_cfg(GemmArgs& g, hipStream_t st) {
+template <int MODE, int WM, int WN, int MI, int NI, int H16>
+static int launch_bf16x3_h(GemmArgs& g, hipStream_t st) {
   constexpr int BN = WN * NI * 32;
   constexpr size_t lds = 2 * (2 * BM * 80);
   static bool attr_set[OFX_MAX_DEVICES] = {};
   if (lds > 64 * 1024 &&      // e.g. 68 KB for BN = 128: above the 64 KB default cap
-      !ofx_raise_lds_limit(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<MODE, WM, WN, MI, NI>), (int)lds, attr_set))
+      !ofx_raise_lds_limit(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<MODE, WM, WN, MI, NI, H16>), (int)lds, attr_set))
     return OFX_ELAUNCH;
-  gemm_bf16x3_kernel<MODE, WM, WN, MI, NI><<<g.ntm * g.ntn * g.nsplit, 256, lds, st>>>(g);
+  gemm_bf16x3_kernel<MODE, WM, WN, MI, NI, H16><<<g.ntm * g.ntn * g.nsplit, 256, lds, st>>>(g);
   return OFX_OK;
+}
+template <int MODE, int WM, int WN, int MI, int NI>
+static int launch_bf16x3_cfg(GemmArgs& g, hipStream_t st) {
+  return g_precision == 3 ? launch_bf16x3_h<MODE, WM, WN, MI, NI, 1>(g, st) : launch_bf16x3_h<MODE, WM, WN, MI, NI, 0>(g, st);
 }
 
 // second stage of the fused statistics.  Block = 64 consecutive wave rows x 64 columns; thread (rg, c) adds up

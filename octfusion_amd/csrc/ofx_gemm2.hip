@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
   for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int t = PREC == 2 ? (u == 0 ? c : 2 + c) : 2 * c + u;
+      const int t = g2_three_term<PREC>() ? (u == 0 ? c : 2 + c) : 2 * c + u;
       const int po = ((2 * t + h) ^ s7) * 16;
       fa[c][u] = lds0 + (wm * 64 + l31) * G2_LINE + po;
       fb[c][u] = lds0 + G2_A_BYTES + (wn * (32 * G2_NI) + l31) * G2_LINE + po;
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
       acc[0][0] = g2_mfma<PREC>(F.a[0][0], F.b[0][0], acc[0][0]);
       return;
     }
-    if (PREC == 2) {
+    if (g2_three_term<PREC>()) {
       // [0] = hi, [1] = lo: small cross terms first, the leading term last
 #pragma unroll
       for (int i = 0; i < G2_MI; ++i)
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
   auto mfma_one = [&](const Half& F, auto m_tag) {
     constexpr int m = decltype(m_tag)::value;
     constexpr int per = G2_MI * G2_NI, t = m / per, i = (m / G2_NI) % G2_MI, j = m % G2_NI;
-    if constexpr (PREC == 2) {
+    if constexpr (g2_three_term<PREC>()) {
       if constexpr (t == 0) acc[i][j] = g2_mfma<PREC>(F.a[1][i], F.b[0][j], acc[i][j]);
       else if constexpr (t == 1) acc[i][j] = g2_mfma<PREC>(F.a[0][i], F.b[1][j], acc[i][j]);
       else acc[i][j] = g2_mfma<PREC>(F.a[0][i], F.b[0][j], acc[i][j]);
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
                                        16, 0, 0);
     }
   };
-  constexpr int NMF = (PREC == 2 ? 3 : 2) * G2_MI * G2_NI;           // MFMAs per half step
+  constexpr int NMF = (g2_three_term<PREC>() ? 3 : 2) * G2_MI * G2_NI;           // MFMAs per half step
   // MFMAs of half Fc with (a) the LDS reads of the NEXT half set Fr (from stage ob_r, half c_r) and (b) optionally the
   // DMA request of tile T spliced between them, in a pinned order: the reads / requests issue in the shadow of the
   // matrix pipe instead of in front of it (variant 5; the un-spliced order leaves the pipe idle while a wave issues
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
   // the last k-steps; its barrier lets those (and, with 3 stages, the 6 new DMA) stay outstanding.
   G2Epi<G2_MI, G2_NI> P;
   const bool vec4 = g.vec4 != 0;
-  constexpr int MFMAS = (PREC == 2 ? 3 : 2) * G2_MI * G2_NI;
+  constexpr int MFMAS = (g2_three_term<PREC>() ? 3 : 2) * G2_MI * G2_NI;
   constexpr int MFMA_PER_ROUND = MFMAS / G2_GLDS_PER_STEP > 0 ? MFMAS / G2_GLDS_PER_STEP : 1;
   auto interleave_dma = [&]() {
     // rounds of {MFMAs, address arithmetic, 1 DMA}: the DMA issues ride in the MFMAs' shadow
@@ -534,18 +534,6 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
 
 // ------------------------------------------------------------------------------------------------
 // plane conversion helpers
-__device__ __forceinline__ unsigned g2_pk_bf16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ unsigned g2_pk_f16(float a, float b) {
-  const _Float16 x = (_Float16)a, y = (_Float16)b;
-  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
-}
-__device__ __forceinline__ float g2_bf16_lo(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float g2_bf16_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
-
 // fp32 [n, C] (zero-extended to Cpad columns) -> planes.  mode 2: lane q of every 8-lane group owns channels
 // 4q..4q+3 of a 32-channel chunk (one coalesced 128-B line in, 64 B hi + 64 B lo out, safe in place);
 // mode 1: fp16 row-major (8 B per lane).
@@ -564,10 +552,10 @@ __global__ void __launch_bounds__(256) planes_split_kernel(const float* __restri
       if (c + 1 < C) v.y = x[r * ldx + c + 1];
       if (c + 2 < C) v.z = x[r * ldx + c + 2];
     }
-    if (mode == 2) {
-      const unsigned h0 = g2_pk_bf16(v.x, v.y), h1 = g2_pk_bf16(v.z, v.w);
-      const unsigned l0 = g2_pk_bf16(v.x - g2_bf16_lo(h0), v.y - g2_bf16_hi(h0));
-      const unsigned l1 = g2_pk_bf16(v.z - g2_bf16_lo(h1), v.w - g2_bf16_hi(h1));
+    if (g2_pairs(mode)) {
+      unsigned h0, h1, l0, l1;
+      g2_split2(mode, v.x, v.y, h0, l0);
+      g2_split2(mode, v.z, v.w, h1, l1);
       char* o = out + r * ldo + (c >> 5) * 128 + (c & 31) * 2;
       *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(o + 64) = make_uint2(l0, l1);
@@ -579,9 +567,9 @@ __global__ void __launch_bounds__(256) planes_split_kernel(const float* __restri
 
 extern "C" int ofx_planes_split(const float* x, int64_t ldx, int64_t n, int C, int Cpad, int mode, void* out,
                                 int64_t ldo_bytes, void* stream) {
-  const int chunk = mode == 2 ? 32 : 64;
-  if ((mode != 1 && mode != 2) || n < 0 || C < 1 || Cpad < C || (Cpad % chunk) || ldx < C || !out ||
-      ldo_bytes < (int64_t)Cpad * (mode == 2 ? 4 : 2) || (ldo_bytes & 15) || ((uintptr_t)out & 15) || (n > 0 && !x))
+  const int chunk = g2_pairs(mode) ? 32 : 64;
+  if (mode < 1 || mode > 3 || n < 0 || C < 1 || Cpad < C || (Cpad % chunk) || ldx < C || !out ||
+      ldo_bytes < (int64_t)Cpad * (g2_pairs(mode) ? 4 : 2) || (ldo_bytes & 15) || ((uintptr_t)out & 15) || (n > 0 && !x))
     return OFX_EINVAL;
   if (C >= 4 && ((ldx & 3) || ((uintptr_t)x & 15))) return OFX_EINVAL;
   if (n > 0)
@@ -599,9 +587,10 @@ __global__ void __launch_bounds__(256) planes_merge_kernel(const char* __restric
     const int64_t r = t / C;
     const int c = (int)(t - r * C);
     float v;
-    if (mode == 2) {
+    if (g2_pairs(mode)) {
       const unsigned short* q = reinterpret_cast<const unsigned short*>(p + r * ldp + (c >> 5) * 128 + (c & 31) * 2);
-      v = __uint_as_float((unsigned)q[0] << 16) + __uint_as_float((unsigned)q[32] << 16);
+      float vb;
+      g2_join2(mode, q[0], q[32], v, vb);
     } else {
       v = (float)*reinterpret_cast<const _Float16*>(p + r * ldp + c * 2);
     }
@@ -610,8 +599,8 @@ __global__ void __launch_bounds__(256) planes_merge_kernel(const char* __restric
 }
 extern "C" int ofx_planes_merge(const void* planes, int64_t ldp_bytes, int64_t n, int C, int mode, float* out,
                                 int64_t ldo, void* stream) {
-  const int chunk = mode == 2 ? 32 : 64;
-  if ((mode != 1 && mode != 2) || n < 0 || C < 1 || (C % chunk) || !planes || !out || ldo < C) return OFX_EINVAL;
+  const int chunk = g2_pairs(mode) ? 32 : 64;
+  if (mode < 1 || mode > 3 || n < 0 || C < 1 || (C % chunk) || !planes || !out || ldo < C) return OFX_EINVAL;
   if (n > 0)
     planes_merge_kernel<<<ofx_grid(n * C, 256), 256, 0, ofx_stream(stream)>>>((const char*)planes, ldp_bytes, n, C,
                                                                               mode, out, ldo);
@@ -633,19 +622,21 @@ __global__ void __launch_bounds__(256) planes_multi_mean_kernel(const char* __re
     const int c = (int)(t - v * c8n) * 8;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // byte offset of this 8-channel piece inside a row
-    const int64_t poff = mode == 2 ? (int64_t)(c >> 5) * 128 + (c & 31) * 2 : (int64_t)c * 2;
+    const int64_t poff = g2_pairs(mode) ? (int64_t)(c >> 5) * 128 + (c & 31) * 2 : (int64_t)c * 2;
     if (v > 0) {
       const int64_t s = multi_seg[v - 1];
       const int32_t b = seg_ptr[s], e = seg_ptr[s + 1];
       for (int32_t p = b; p < e; ++p) {
         const char* row = xp + (int64_t)col[p] * ldx + poff;
         const u32x4 hi = *reinterpret_cast<const u32x4*>(row);
-        if (mode == 2) {
+        if (g2_pairs(mode)) {
           const u32x4 lo = *reinterpret_cast<const u32x4*>(row + 64);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            acc[2 * k] += g2_bf16_lo(hi[k]) + g2_bf16_lo(lo[k]);
-            acc[2 * k + 1] += g2_bf16_hi(hi[k]) + g2_bf16_hi(lo[k]);
+            float va, vb;
+            g2_join2(mode, hi[k], lo[k], va, vb);
+            acc[2 * k] += va;
+            acc[2 * k + 1] += vb;
           }
         } else {
 #pragma unroll
@@ -660,12 +651,13 @@ __global__ void __launch_bounds__(256) planes_multi_mean_kernel(const char* __re
       for (int k = 0; k < 8; ++k) acc[k] *= inv;
     }
     char* o = aux + v * ldx + poff;
-    if (mode == 2) {
+    if (g2_pairs(mode)) {
       u32x4 hi, lo;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        hi[k] = g2_pk_bf16(acc[2 * k], acc[2 * k + 1]);
-        lo[k] = g2_pk_bf16(acc[2 * k] - g2_bf16_lo(hi[k]), acc[2 * k + 1] - g2_bf16_hi(hi[k]));
+        unsigned hh, ll;
+        g2_split2(mode, acc[2 * k], acc[2 * k + 1], hh, ll);
+        hi[k] = hh; lo[k] = ll;
       }
       *reinterpret_cast<u32x4*>(o) = hi;
       *reinterpret_cast<u32x4*>(o + 64) = lo;
@@ -681,7 +673,7 @@ __global__ void __launch_bounds__(256) planes_multi_mean_kernel(const char* __re
 // ------------------------------------------------------------------------------------------------
 // weights -> [k tile][column][128-B line]; k order of the fused GraphConv: 7 x cin gathered channels
 // (direction-major), then the node-type rows padded to a whole tile.
-static inline int64_t g2_chunk(int mode) { return mode == 2 ? 32 : 64; }
+static inline int64_t g2_chunk(int mode) { return g2_pairs(mode) ? 32 : 64; }
 extern "C" int64_t ofx_planes_packed_ktiles(int cin, int nt, int mode) {
   const int64_t ch = g2_chunk(mode);
   return 7 * ((int64_t)cin / ch) + (nt > 1 ? (7 * (int64_t)nt + ch - 1) / ch : 0);
@@ -695,12 +687,12 @@ __global__ void __launch_bounds__(256) planes_pack_kernel(const float* __restric
                                                           char* __restrict__ out) {
   // one thread per 16-B piece: (k tile, column, piece)
   const int64_t total = nkt * N * 8;
-  const int ch = mode == 2 ? 32 : 64;
+  const int ch = g2_pairs(mode) ? 32 : 64;
   const int64_t Kf = 7 * (int64_t)cin;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int p = (int)(t & 7);
     const int64_t n = (t >> 3) % N, kt = (t >> 3) / N;
-    const int64_t k0 = kt * ch + (mode == 2 ? (p & 3) * 8 : p * 8);
+    const int64_t k0 = kt * ch + (g2_pairs(mode) ? (p & 3) * 8 : p * 8);
     float w[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -716,11 +708,12 @@ __global__ void __launch_bounds__(256) planes_pack_kernel(const float* __restric
       w[e] = src >= 0 ? W[src * sk + n * sn] : 0.f;
     }
     u32x4 o;
-    if (mode == 2) {
+    if (g2_pairs(mode)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const unsigned hi = g2_pk_bf16(w[2 * e], w[2 * e + 1]);
-        o[e] = p < 4 ? hi : g2_pk_bf16(w[2 * e] - g2_bf16_lo(hi), w[2 * e + 1] - g2_bf16_hi(hi));
+        unsigned hi, lo;
+        g2_split2(mode, w[2 * e], w[2 * e + 1], hi, lo);
+        o[e] = p < 4 ? hi : lo;
       }
     } else {
 #pragma unroll
@@ -732,7 +725,7 @@ __global__ void __launch_bounds__(256) planes_pack_kernel(const float* __restric
 
 extern "C" int ofx_pack_weights_planes(const float* W, int64_t sk, int64_t sn, int cin, int nt, int cout, int mode,
                                        void* out, void* stream) {
-  if (!W || !out || (mode != 1 && mode != 2) || cin < 1 || (cin % g2_chunk(mode)) || nt < 0 || cout < 1 ||
+  if (!W || !out || mode < 1 || mode > 3 || cin < 1 || (cin % g2_chunk(mode)) || nt < 0 || cout < 1 ||
       ((uintptr_t)out & 15))
     return OFX_EINVAL;
   const int64_t nkt = ofx_planes_packed_ktiles(cin, nt, mode);
@@ -825,11 +818,11 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
                                         const float* res, int64_t ldr, float* out, int64_t ldc, double* stats,
                                         int64_t stats_ld, void* ws, size_t ws_bytes, void* sync, size_t sync_bytes,
                                         int mode, int aux_ready, void* stream) {
-  if (mode != 1 && mode != 2) return OFX_EINVAL;
+  if (mode < 1 || mode > 3) return OFX_EINVAL;
   const int64_t ch = g2_chunk(mode);
   if (n_nodes == 0 && cin >= 1 && cout >= 1) return OFX_OK;
   if (n_nodes < 0 || cin < 1 || (cin % ch) || cout < 1 || !xp || !seg_ptr || !col || !nbr_ext || !aux || !W2 || !out ||
-      ldx_bytes < (int64_t)cin * (mode == 2 ? 4 : 2) || (ldx_bytes & 127) || ((uintptr_t)xp & 127) ||
+      ldx_bytes < (int64_t)cin * (g2_pairs(mode) ? 4 : 2) || (ldx_bytes & 127) || ((uintptr_t)xp & 127) ||
       ((uintptr_t)aux & 127) || ((uintptr_t)W2 & 127) || ldc < cout || (res && ldr < cout) ||
       (emb && (!batch_id || lde < cout)) || n_multi < 0 || (n_multi > 0 && !multi_seg) || nt < 0)
     return OFX_EINVAL;
@@ -892,9 +885,10 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
         default: return G2_GO(2, 5, wm);
       }
     }
+    if (mode == 3) return G2_GO(3, 5, wm);
     return g2_variant == 0 ? G2_GO(1, 0, wm) : (g2_variant == 1 ? G2_GO(1, 1, wm) : G2_GO(1, 5, wm));
 #else
-    return mode == 2 ? G2_GO(2, 5, wm) : G2_GO(1, 5, wm);     // the spliced schedule is the only one in product builds
+    return mode == 2 ? G2_GO(2, 5, wm) : (mode == 3 ? G2_GO(3, 5, wm) : G2_GO(1, 5, wm));   // (the spliced schedule is the only one in product builds)
 #endif
   };
   // narrow layers on very long tensors (depth 7 / 8 of the feature net: >= 8 rounds of 256-row tiles) amortise the

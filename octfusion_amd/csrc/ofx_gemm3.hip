@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
   for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int uu = 0; uu < 2; ++uu) {
-      const int t = PREC == 2 ? (uu == 0 ? c : 2 + c) : 2 * c + uu;
+      const int t = g2_three_term<PREC>() ? (uu == 0 ? c : 2 + c) : 2 * c + uu;
       const int po = ((2 * t + h) ^ s7) * 16;
       fa[c][uu] = lds0 + (wm * 64 + l31) * G2_LINE + po;
       fb[c][uu] = lds0 + G2_A_BYTES + (wn * (32 * G2_NI) + l31) * G2_LINE + po;
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
   auto mfma_one = [&](const Half& F, auto m_tag) {
     constexpr int m = decltype(m_tag)::value;
     constexpr int per = G2_MI * G2_NI, t = m / per, i = (m / G2_NI) % G2_MI, j = m % G2_NI;
-    if constexpr (PREC == 2) {
+    if constexpr (g2_three_term<PREC>()) {
       // [0] = hi, [1] = lo: small cross terms first, the leading term last
       if constexpr (t == 0) acc[i][j] = g2_mfma<PREC>(F.a[1][i], F.b[0][j], acc[i][j]);
       else if constexpr (t == 1) acc[i][j] = g2_mfma<PREC>(F.a[0][i], F.b[1][j], acc[i][j]);
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
                                        16, 0, 0);
     }
   };
-  constexpr int NMF = (PREC == 2 ? 3 : 2) * G2_MI * G2_NI;           // MFMAs per half step
+  constexpr int NMF = (g2_three_term<PREC>() ? 3 : 2) * G2_MI * G2_NI;           // MFMAs per half step
   // MFMAs of half Fc with (a) the LDS reads of the next half set Fr and (b) optionally the DMA request of tile T
   // spliced between them in a pinned order (gconv2's "variant 5").
   auto mfma_spliced = [&](const Half& Fc, bool do_read, int ob_r, int c_r, Half& Fr, auto dma_tag, const Tile& T,
@@ -721,6 +721,6 @@ int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, siz
 #define G3_GO(P_)                                                                                         \
   (ni == 1 ? (wm == 4 ? g3_launch<P_, 4, 1>(A, st) : g3_launch<P_, 2, 1>(A, st))                          \
            : (wm == 4 ? g3_launch<P_, 4, 2>(A, st) : g3_launch<P_, 2, 2>(A, st)))
-  return mode == 2 ? G3_GO(2) : G3_GO(1);
+  return mode == 2 ? G3_GO(2) : (mode == 3 ? G3_GO(3) : G3_GO(1));
 #undef G3_GO
 }

@@ -8,7 +8,7 @@
 // inv_count = 1/(count*cpg + eps), mean = S*inv_count, centred variance
 // sum((x-mean)^2)*inv_count = (SS - 2*mean*S + n*mean^2)*inv_count evaluated in
 // fp64, rstd = 1/sqrt(var + eps).
-#include "ofx_common.h"
+#include "ofx_planes.h"     // the 16-bit operand-pair formats of the planes GraphConv (g2_split2)
 
 // 64 rows per block: the kernel is latency/MLP-bound, not atomic-bound -- it needs >> 256 CUs x 8
 // resident blocks with several 16-B loads in flight per lane (a 512-row block left 1.6 blocks per CU
@@ -158,11 +158,6 @@ __device__ __forceinline__ float ofx_apply_act(float v, int act) {
 // alias an fp32-shaped buffer, including x itself (a thread reads its 16 B of the chunk and writes 8 B of each half;
 // the 8 threads of a chunk are lanes of one wave instruction, whose loads all return before its stores issue);
 // 1 = fp16 row-major.
-__device__ __forceinline__ unsigned gn_pk_bf16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 constexpr int GN_APPLY_ROWS = 64;
 // (mean, rstd) of one (batch element, group) from the fp64 sums -- the arithmetic of gn_finalize_kernel, so a launch
 // that finalises on the fly (FIN) gives the same bits as ofx_gn_finalize + a launch that reads mean / rstd.
@@ -258,10 +253,10 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
   auto store = [&](char* orow, const float4& y) {
     if (MODE == 0) {
       *reinterpret_cast<float4*>(orow + (int64_t)c * 4) = y;
-    } else if (MODE == 2) {
-      const unsigned h0 = gn_pk_bf16(y.x, y.y), h1 = gn_pk_bf16(y.z, y.w);
-      const unsigned l0 = gn_pk_bf16(y.x - __uint_as_float(h0 << 16), y.y - __uint_as_float(h0 & 0xffff0000u));
-      const unsigned l1 = gn_pk_bf16(y.z - __uint_as_float(h1 << 16), y.w - __uint_as_float(h1 & 0xffff0000u));
+    } else if (MODE == 2 || MODE == 3) {
+      unsigned h0, h1, l0, l1;
+      g2_split2(MODE, y.x, y.y, h0, l0);
+      g2_split2(MODE, y.z, y.w, h1, l1);
       char* o = orow + (c >> 5) * 128 + (c & 31) * 2;
       *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(o + 64) = make_uint2(l0, l1);
@@ -366,10 +361,10 @@ extern "C" int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C
                                    int groups, float eps, float count_eps, const float* w, const float* bias, int act,
                                    int mode, void* out, int64_t ldo_bytes, const int32_t* seg_ptr, const int32_t* col,
                                    const int32_t* multi_seg, int64_t n_multi, void* aux, void* stream) {
-  const int chunk = mode == 2 ? 32 : 64;
+  const int chunk = g2_pairs(mode) ? 32 : 64;
   GnFin f = {nullptr, nullptr, 1, eps, count_eps};
-  if ((mode != 1 && mode != 2) || !x || !batch_id || !w || !bias || !out || n < 0 || C < chunk ||
-      (C % chunk) || C > 1024 || ldx < C || (ldx & 3) || ldo_bytes < (int64_t)C * (mode == 2 ? 4 : 2) ||
+  if (mode < 1 || mode > 3 || !x || !batch_id || !w || !bias || !out || n < 0 || C < chunk ||
+      (C % chunk) || C > 1024 || ldx < C || (ldx & 3) || ldo_bytes < (int64_t)C * (g2_pairs(mode) ? 4 : 2) ||
       (ldo_bytes & 15) || ((uintptr_t)x & 15) || ((uintptr_t)out & 127) || ((uintptr_t)w & 15) ||
       ((uintptr_t)bias & 15) || act < 0 || act > 2 || !gn_fin_args(mean, rstd, sums, count, C, groups, f))
     return OFX_EINVAL;
@@ -385,6 +380,7 @@ extern "C" int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C
   gn_apply_kernel<M_, F_><<<grid, 256, 0, st>>>(x, ldx, n, C, batch_id, mean, rstd, f, w, bias, act, (char*)out,   \
                                                 ldo_bytes, ab, seg_ptr, col, multi_seg, n_multi, (char*)aux)
     if (mode == 2) { if (mean) GN_GO(2, false); else GN_GO(2, true); }
+    else if (mode == 3) { if (mean) GN_GO(3, false); else GN_GO(3, true); }
     else { if (mean) GN_GO(1, false); else GN_GO(1, true); }
 #undef GN_GO
   }

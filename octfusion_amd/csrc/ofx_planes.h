@@ -13,6 +13,43 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef const char __attribute__((address_space(1)))* gcp;
 typedef __attribute__((address_space(3))) void* ldsp;
 
+// ---- 16-bit operand pairs.  A value travels as hi + lo, both in the same 16-bit format:
+//   mode 2: bf16 pairs (8 + 8 significand bits: a = hi + lo to 2^-18 relative) -- "bf16x3";
+//   mode 3: fp16 pairs (11 + 11 bits: a = hi + lo to 2^-23 relative while lo is a normal fp16, to 2^-25 ABSOLUTE
+//           below -- v_mfma_f32_32x32x16_f16 honours fp16 denormal inputs on gfx950, tools/probes/mfma_f16_denorm.hip)
+//           -- "fp16x3": the same three MFMAs per product, ~30x less rounding than bf16x3.  Values are saturated to the
+//           fp16 range (+-65504) first: normalised activations and weights are many orders of magnitude below it.
+__device__ __forceinline__ unsigned g2_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned g2_pk_f16(float a, float b) {
+  const _Float16 x = (_Float16)a, y = (_Float16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ float g2_bf16_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float g2_bf16_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+__device__ __forceinline__ float g2_f16_lo(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
+__device__ __forceinline__ float g2_f16_hi(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
+__device__ __forceinline__ float g2_sat16(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
+// (a, b) -> packed hi pair + packed lo pair
+__device__ __forceinline__ void g2_split2(int mode, float a, float b, unsigned& hi, unsigned& lo) {
+  if (mode == 3) {
+    a = g2_sat16(a); b = g2_sat16(b);
+    hi = g2_pk_f16(a, b);
+    lo = g2_pk_f16(a - g2_f16_lo(hi), b - g2_f16_hi(hi));
+  } else {
+    hi = g2_pk_bf16(a, b);
+    lo = g2_pk_bf16(a - g2_bf16_lo(hi), b - g2_bf16_hi(hi));
+  }
+}
+__device__ __forceinline__ void g2_join2(int mode, unsigned hi, unsigned lo, float& a, float& b) {
+  if (mode == 3) { a = g2_f16_lo(hi) + g2_f16_lo(lo); b = g2_f16_hi(hi) + g2_f16_hi(lo); }
+  else { a = g2_bf16_lo(hi) + g2_bf16_lo(lo); b = g2_bf16_hi(hi) + g2_bf16_hi(lo); }
+}
+__host__ __device__ static inline bool g2_pairs(int mode) { return mode == 2 || mode == 3; }   // [hi x 32 | lo x 32] lines
+
 // Two block geometries (template parameter WM = wave rows):
 //   WM = 4: 256 x 128 tile, 8 waves, 3 stage buffers (DMA two k-steps ahead), 152 KB LDS -> ONE block per CU;
 //   WM = 2: 128 x 128 tile, 4 waves, 2 stage buffers (DMA one k-step ahead),  68 KB LDS -> TWO blocks per CU: the
@@ -78,6 +115,10 @@ __device__ __forceinline__ void g2_static_for(F&& f) {
 template <int PREC> struct G2Frag;
 template <> struct G2Frag<2> { typedef bf16x8_t T; };
 template <> struct G2Frag<1> { typedef f16x8_t T; };
+template <> struct G2Frag<3> { typedef f16x8_t T; };      // fp16 hi / lo pairs: the three-term scheme on the fp16 pipe
+// PREC 2 / 3: a line is [hi x 32 | lo x 32] of a 32-channel chunk and a product takes three MFMAs; PREC 1: a line is
+// 64 fp16 channels, one MFMA per product.
+template <int PREC> constexpr bool g2_three_term() { return PREC >= 2; }
 
 template <int PREC>
 __device__ __forceinline__ f32x16 g2_mfma(typename G2Frag<PREC>::T a, typename G2Frag<PREC>::T b, f32x16 c);
@@ -87,6 +128,10 @@ __device__ __forceinline__ f32x16 g2_mfma<2>(bf16x8_t a, bf16x8_t b, f32x16 c) {
 }
 template <>
 __device__ __forceinline__ f32x16 g2_mfma<1>(f16x8_t a, f16x8_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16 g2_mfma<3>(f16x8_t a, f16x8_t b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 

@@ -373,8 +373,8 @@ class UNet3DModel(nn.Module):
 
     @torch.no_grad()
     def forward_rows(self, x, batch_size, timesteps, label=None, as_middle=False):
-        """x [B*8^full_depth, C] in node-row layout; returns rows at full_depth.  Runs under ops.POLICY['dense_net']
-        (default: exact fp32 -- this net is launch-bound, and bf16x3 here is where a whole step loses most accuracy)."""
+        """x [B*8^full_depth, C] in node-row layout; returns rows at full_depth.  (ops.POLICY['dense_net'] can move this
+        net to another contraction mode when the global mode is 'bf16x3' -- an instrument of the precision study.)"""
         with ops.policy_scope('dense_net'):
             return self._forward_rows(x, batch_size, timesteps, label, as_middle)
 

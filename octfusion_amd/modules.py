@@ -57,10 +57,10 @@ class GraphConv(nn.Module):
         mode = ops.planes_mode()
         if not mode:
             return 0
-        cin = self.in_channels if cin is None else (cin if mode == 2 else 64)
+        cin = self.in_channels if cin is None else (cin if ops.planes_pairs(mode) else 64)
         N = doctree.csr(d)[2]
         tiles = ((N + 255) // 256) * ((self.out_channels + 127) // 128)
-        if (cin % (32 if mode == 2 else 64) or self.out_channels % 4 or self.out_channels < 64 or
+        if (cin % (32 if ops.planes_pairs(mode) else 64) or self.out_channels % 4 or self.out_channels < 64 or
                 tiles < ops.PLANES_MIN_TILES):
             return 0
         return mode
@@ -98,7 +98,7 @@ class GraphConv(nn.Module):
             # dense GEMM (graph_unet_hr.py:116, modules.py:199-213)
             mode = self.planes_mode(doctree, d, cin=32)
             if mode:
-                cin_k = 32 if mode == 2 else 64
+                cin_k = 32 if ops.planes_pairs(mode) else 64
                 x = ops.planes_split(x, mode, Cpad=cin_k)
         if mode:
             pw2 = self._pw2.get(self.weights, self.in_channels, nt, mode, cin_pad=cin_k)
@@ -144,7 +144,7 @@ class DualOctreeGroupNorm(nn.Module):
         the aux rows (zero row + multi-neighbour means) that convolution gathers besides the tensor itself."""
         assert doctree.batch_id32(depth).shape[0] == data.shape[0]
         stats = ops.get_stats(data)
-        if planes == 2 and out is not None and not ops.planes_ok(out, 2):
+        if ops.planes_pairs(planes) and out is not None and not ops.planes_ok(out, planes):
             out = None
         aux_graph = None
         if planes:

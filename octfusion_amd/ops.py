@@ -45,12 +45,16 @@ def _row_major(t):
 _WS = {}
 
 
-PRECISIONS = {'bf16x3': 0, 'fp32': 1, 'fp16': 2}
+PRECISIONS = {'bf16x3': 0, 'fp32': 1, 'fp16': 2, 'fp16x3': 3}
+DEFAULT_PRECISION = 'fp16x3'
 
 
 def set_precision(mode):
-    """'bf16x3' (default: fp32-class accuracy on the bf16 matrix pipe), 'fp32' (exact fp32 MFMA) or
-    'fp16' (reduced precision: single-pass fp16 MFMA in the planes GraphConv, everything else bf16x3)."""
+    """'fp16x3' (default): operands as fp16 hi + lo pairs, three fp16 MFMAs per product, fp32 accumulate -- the fp32
+    reference's rounding class (~2^-21 per product) on the 16-bit matrix pipe;
+    'bf16x3': the same scheme with bf16 pairs (2^-16 per product; rounds 1-2's default, kept for A/B);
+    'fp32' (exact fp32 MFMA); 'fp16' (reduced precision: single-pass fp16 MFMA in the planes GraphConv, everything
+    else bf16x3)."""
     call('ofx_set_precision', PRECISIONS[mode])
 
 
@@ -59,16 +63,13 @@ def get_precision():
     return [k for k, v in PRECISIONS.items() if v == code][0]
 
 
-# Precision policy of the DEFAULT mode ('bf16x3'): which parts of a step run in exact fp32 instead.  bf16x3 products
-# carry 16 significant bits per operand; through a whole denoising step that is ~10x the rounding noise of the
-# reference's own fp32 arithmetic (profiles/r03/oracle_fp32_noise.json, precision_attribution.json).  The parts that
-# are launch-bound anyway cost (almost) nothing in exact fp32:
-#   'dense_net' : the dense 16^3 / 8^3 / 4^3 U-Net (stage lr, and nested as the middle of stage hr) -- every GEMM,
-#                 27-tap convolution and 1x1 of it (its attention kernel is fp32 MFMA in every mode);
-#   'small_gemm': GEMMs / register-staged GraphConvs with <= 64 output or input channels (bf16x3 buys nothing there).
-# The wide GraphConvs (the planes kernel: > 95 % of the flops) stay bf16x3.  A policy entry of None follows the global
-# mode; the policy is ignored when the global mode is not 'bf16x3'.
-POLICY = {'dense_net': 'fp32', 'small_gemm': 'fp32'}
+# Precision policy: parts of a step that run in another mode than the global one WHEN the global mode is 'bf16x3'
+# (an A/B instrument of the precision study, profiles/r03/precision_attribution.json: with bf16 pairs the dense lr net
+# is where a stand-alone lr step loses its accuracy -- element-wise p99.9 8.9e-3 -> 4.9e-4 with that net in exact fp32
+# -- while the hr step's error sits in the wide GraphConvs).  The default mode 'fp16x3' needs no such help and ignores
+# the policy.  Keys: 'dense_net' (the dense 16^3 U-Net as a stand-alone stage), 'small_gemm' (GEMMs / register-staged
+# GraphConvs with <= 64 channels).
+POLICY = {'dense_net': None, 'small_gemm': None}
 
 
 @contextlib.contextmanager
@@ -97,7 +98,13 @@ def planes_mode():
     if not USE_PLANES:
         return 0
     code = _lib.lib().ofx_get_precision()
-    return {0: 2, 1: 0, 2: 1}[code]
+    return {0: 2, 1: 0, 2: 1, 3: 3}[code]
+
+
+def planes_pairs(mode):
+    """modes 2 (bf16) / 3 (fp16): a 128-B line is [hi x 32 | lo x 32] of a 32-channel chunk -- the bytes of the fp32
+    row, so the planes alias an fp32-shaped buffer; mode 1: fp16 row-major, 64 channels per line."""
+    return mode in (2, 3)
 
 
 def planes_of(t):
@@ -105,12 +112,12 @@ def planes_of(t):
 
 
 def _planes_chunk(mode):
-    return 32 if mode == 2 else 64
+    return 32 if planes_pairs(mode) else 64
 
 
 def _planes_out(n, C, mode, device, out=None):
     """(tensor, row pitch in bytes) for a planes tensor of n rows x C channels."""
-    if mode == 2:
+    if planes_pairs(mode):
         if out is None:
             out = torch.empty(n, C, dtype=torch.float32, device=device)
         assert out.dtype == torch.float32 and out.shape == (n, C) and out.stride(1) == 1
@@ -123,8 +130,8 @@ def _planes_out(n, C, mode, device, out=None):
 
 
 def planes_ok(t, mode):
-    """can tensor `t` (fp32 [n, C]) be overwritten in place by its mode-2 planes?"""
-    return (mode == 2 and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and
+    """can tensor `t` (fp32 [n, C]) be overwritten in place by its hi / lo pair planes (modes 2, 3)?"""
+    return (planes_pairs(mode) and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and
             t.data_ptr() % 128 == 0 and (t.stride(0) * 4) % 128 == 0 and t.shape[1] % 32 == 0)
 
 
@@ -144,7 +151,7 @@ def planes_merge(p, mode=None):
     """planes -> fp32 [n, C] (tests)."""
     mode = mode or planes_of(p)
     n, C = p.shape
-    ld = p.stride(0) * (4 if mode == 2 else 2)
+    ld = p.stride(0) * (4 if planes_pairs(mode) else 2)
     out = torch.empty(n, C, dtype=torch.float32, device=p.device)
     call('ofx_planes_merge', ptr(p), ld, n, C, mode, ptr(out), C, stream())
     return out
@@ -191,7 +198,8 @@ def graphconv_planes(xp, mode, seg_ptr, col, ext, pw, cin, nt, tf_planes=None, b
     """Fused GraphConv on operand planes (ofx_graphconv_fwd_planes)."""
     assert planes_of(xp) == mode and xp.shape[1] == cin
     N = xp.shape[0]
-    ldx = xp.stride(0) * (4 if mode == 2 else 2) if N > 1 else cin * (4 if mode == 2 else 2)
+    bpc = 4 if planes_pairs(mode) else 2
+    ldx = xp.stride(0) * bpc if N > 1 else cin * bpc
     if out is None:
         out = torch.empty(N, pw.N, dtype=torch.float32, device=xp.device)
     out2, ldc = _row_major(out)
@@ -210,7 +218,7 @@ def graphconv_planes(xp, mode, seg_ptr, col, ext, pw, cin, nt, tf_planes=None, b
     if res is not None:
         res, ldr = _row_major(res)
     if tf_planes is not None:
-        ldt = tf_planes.stride(0) * (4 if mode == 2 else 2)
+        ldt = tf_planes.stride(0) * bpc
     _chk(bias)
     _chk(stats, torch.float64)
     prof = GRAPHCONV_PROFILE
@@ -227,10 +235,10 @@ def graphconv_planes(xp, mode, seg_ptr, col, ext, pw, cin, nt, tf_planes=None, b
     if prof is not None:
         e1.record()
         E = col.numel()
-        s_in = 4.0 if mode == 2 else 2.0
+        s_in = 4.0 if planes_pairs(mode) else 2.0
         flops = 2.0 * N * pw.K * pw.N
         nbytes = s_in * (E * pw.cin + pw.K * pw.N) + 4.0 * N * pw.N + 8.0 * E
-        prof.append((e0, e1, flops, nbytes, pw.N, ('graph2' if mode == 2 else 'graph2h', N, pw.cin, pw.N)))
+        prof.append((e0, e1, flops, nbytes, pw.N, ('graph2' if planes_pairs(mode) else 'graph2h', N, pw.cin, pw.N)))
     return out
 
 
@@ -301,7 +309,8 @@ class PackedWeight:
 
     def get(self, w, mode, cin=0, nt=0):
         """mode 'kn': w is [K, N]; 'nk': w is [N, K] (nn.Linear); 'graphconv': [7*(cin+nt'), N]."""
-        key = (w.data_ptr(), w._version, tuple(w.shape), mode, cin, nt)
+        # (the 16-bit planes behind the fp32 pack are bf16 or fp16 pairs, by the precision at pack time: part of the key)
+        key = (w.data_ptr(), w._version, tuple(w.shape), mode, cin, nt, _lib.lib().ofx_get_precision() == 3)
         if key == self.key:
             return self
         _chk(w)
@@ -520,7 +529,7 @@ class PackedConv3d:
         self.cin = self.N = 0
 
     def get(self, w):
-        key = (w.data_ptr(), w._version, tuple(w.shape))
+        key = (w.data_ptr(), w._version, tuple(w.shape), _lib.lib().ofx_get_precision() == 3)
         if key == self.key:
             return self
         _chk(w)
@@ -650,7 +659,7 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         # multi-neighbour means), which needs a destination other than x.
         if aux_graph is not None and out is not None and out.data_ptr() == x.data_ptr():
             out = None
-        out, ldo = _planes_out(n, C, planes, dev, out if planes == 2 else None)
+        out, ldo = _planes_out(n, C, planes, dev, out if planes_pairs(planes) else None)
         aux = seg_ptr = col = multi_seg = None
         n_multi = 0
         if aux_graph is not None:

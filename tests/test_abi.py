@@ -91,7 +91,7 @@ def test_planes_kernels_have_no_scratch():
         return len(rows), bad
     with ThreadPoolExecutor(2) as ex:
         res = list(ex.map(audit, ['ofx_gemm3.hip', 'ofx_gemm2.hip']))
-    assert res[0][0] == 8 and res[1][0] == 8, res          # 2 precisions x 2 geometries x 2 tile widths each
+    assert res[0][0] == 12 and res[1][0] == 12, res        # 3 contraction modes x 2 geometries x 2 tile widths each
     assert not res[0][1] and not res[1][1], res
 
 

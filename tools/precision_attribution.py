@@ -3,10 +3,11 @@
 One step of the hr net (+ nested lr) and of the lr net at the real widths, under four settings of the contraction
 precision, against the CPU oracle run in float32 (the reference's arithmetic) AND in float64 (the same op sequence,
 exact for this purpose):
-    pure_bf16x3 : every contraction bf16x3 (round 2's default)
-    dense_fp32  : + the dense lr net in exact fp32                       (ops.POLICY['dense_net'])
-    default     : + GEMMs / GraphConvs with <= 64 channels in exact fp32 (ops.POLICY['small_gemm'])  <- the product default
-    fp32        : everything exact fp32 (ofx_set_precision(1))
+    fp16x3 (default): fp16 hi + lo operand pairs, three fp16 MFMAs per product
+    pure_bf16x3     : bf16 pairs everywhere (round 2's default)
+    + dense net fp32: bf16 pairs, the dense lr net in exact fp32          (ops.POLICY['dense_net'])
+    + small layers  : + GEMMs / GraphConvs with <= 64 channels exact fp32  (ops.POLICY['small_gemm'])
+    fp32            : everything exact fp32 (ofx_set_precision(1))
 Figures: rel-to-max, element-wise p99.9 / max with the 1 % floor (tests/test_gpu_fullwidth.errors), eager ms per step.
 
     python tools/precision_attribution.py --out gpurun_out/precision_attribution.json
@@ -31,9 +32,10 @@ from oracle import dual_octree as OD, modules as OM, sampler as OS, unet as OU
 
 torch.set_grad_enabled(False)
 dev = torch.device('cuda:0')
-SETTINGS = [('pure_bf16x3', 'bf16x3', dict(dense_net=None, small_gemm=None)),
-            ('dense_fp32', 'bf16x3', dict(dense_net='fp32', small_gemm=None)),
-            ('default', 'bf16x3', dict(dense_net='fp32', small_gemm='fp32')),
+SETTINGS = [('fp16x3 (default)', 'fp16x3', dict(dense_net=None, small_gemm=None)),
+            ('pure_bf16x3', 'bf16x3', dict(dense_net=None, small_gemm=None)),
+            ('bf16x3 + dense net fp32', 'bf16x3', dict(dense_net='fp32', small_gemm=None)),
+            ('bf16x3 + dense net and small layers fp32', 'bf16x3', dict(dense_net='fp32', small_gemm='fp32')),
             ('fp32', 'fp32', dict(dense_net=None, small_gemm=None))]
 
 
@@ -107,7 +109,7 @@ for cfgname in ('snet_uncond', 'snet_cond'):
                 y = run()
                 ms = timeit(run)
             finally:
-                ops.set_precision('bf16x3')
+                ops.set_precision(ops.DEFAULT_PRECISION)
                 ops.POLICY.update(saved_policy)
             rows.append(dict(step=step, config=cfgname, setting=name, eager_ms=ms,
                              vs_fp32_oracle=figures(y, ref32), vs_fp64_oracle=figures(y, ref64)))

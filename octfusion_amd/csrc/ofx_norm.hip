@@ -197,9 +197,26 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
   __shared__ float fin_ms[FIN ? 2 * 2 * 1024 : 1];       // [slot][mean | rstd][C]
   int fb0 = -1, fb1 = -1;
   const bool is_aux = (int64_t)blockIdx.x < aux_blocks;
+  // the first four rows of this thread are requested BEFORE the statistics are finalised: the rows come from HBM, the
+  // sums from L2, and the block would otherwise sit through a chain of dependent loads + fp64 arithmetic + a barrier
+  // before its first payload byte is even asked for (measured: +23 % on the whole launch)
+  const int64_t r_begin0 = ((int64_t)blockIdx.x - aux_blocks) * GN_APPLY_ROWS;
+  const int64_t r_end0 = r_begin0 + GN_APPLY_ROWS < n ? r_begin0 + GN_APPLY_ROWS : n;
+  const bool pre = FIN && !is_aux && rl < RP && r_begin0 + rl + 3 * (int64_t)RP < r_end0;
+  float4 pv0, pv1, pv2, pv3;
+  int pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0;
+  if (pre) {
+    const int64_t r = r_begin0 + rl;
+    const int c_ = cl * 4;
+    pb0 = bid[r]; pb1 = bid[r + RP]; pb2 = bid[r + 2 * RP]; pb3 = bid[r + 3 * RP];
+    pv0 = *reinterpret_cast<const float4*>(x + r * ldx + c_);
+    pv1 = *reinterpret_cast<const float4*>(x + (r + RP) * ldx + c_);
+    pv2 = *reinterpret_cast<const float4*>(x + (r + 2 * RP) * ldx + c_);
+    pv3 = *reinterpret_cast<const float4*>(x + (r + 3 * RP) * ldx + c_);
+  }
   if (FIN && !is_aux) {
-    const int64_t r_begin = ((int64_t)blockIdx.x - aux_blocks) * GN_APPLY_ROWS;
-    const int64_t r_last = (r_begin + GN_APPLY_ROWS < n ? r_begin + GN_APPLY_ROWS : n) - 1;
+    const int64_t r_begin = r_begin0;
+    const int64_t r_last = r_end0 - 1;
     fb0 = bid[r_begin];
     fb1 = bid[r_last];
     const int cpg = C / fin.G;
@@ -306,9 +323,15 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
     store(aux + v * ldo, acc);
     return;
   }
-  const int64_t r_begin = ((int64_t)blockIdx.x - aux_blocks) * GN_APPLY_ROWS;
-  const int64_t r_end = r_begin + GN_APPLY_ROWS < n ? r_begin + GN_APPLY_ROWS : n;
+  const int64_t r_begin = r_begin0, r_end = r_end0;
   int64_t r = r_begin + rl;
+  if (pre) {
+    store(out + r * ldo, norm(pb0, pv0));
+    store(out + (r + RP) * ldo, norm(pb1, pv1));
+    store(out + (r + 2 * RP) * ldo, norm(pb2, pv2));
+    store(out + (r + 3 * RP) * ldo, norm(pb3, pv3));
+    r += 4 * (int64_t)RP;
+  }
   for (; r + 3 * (int64_t)RP < r_end; r += 4 * (int64_t)RP) {
     const int b0 = bid[r], b1 = bid[r + RP], b2 = bid[r + 2 * RP], b3 = bid[r + 3 * RP];
     const float4 v0 = *reinterpret_cast<const float4*>(x + r * ldx + c);

@@ -90,7 +90,11 @@ def policy_scope(part):
 # ---- operand planes (csrc/ofx_gemm2.hip): the LDS-DMA GraphConv and its producers --------------------
 PLANES_ATTR = '_ofx_planes'
 USE_PLANES = True            # A/B switch: False keeps every GraphConv on the register-staged kernel
-PLANES_MIN_TILES = 128       # 256 x 128 tiles; below this the old kernel (128 x 128 tiles, split-K) fills the chip better
+# 256 x 128 tiles of a layer below which the register-staged kernel (128 x 128 tiles, split-K) is used instead of the
+# planes kernel.  128 until round 3; the persistent stream-K launch balances any tile count over the chip, which moved
+# the break-even down: a ONE-shape hr step (the generate regime) 3.66 -> 3.21 ms at 32, nothing more below
+# (profiles/r03/generate_b1_min_tiles.txt; OFX_PLANES_MIN_TILES: A/B knob of tools/generate_probe.py)
+PLANES_MIN_TILES = int(os.environ.get('OFX_PLANES_MIN_TILES', '32'))
 
 
 def planes_mode():
@@ -622,6 +626,7 @@ def gather_mean(x, seg_ptr, col):
 
 
 AUX_ATTR = '_ofx_aux'
+GN_FINALIZE_LAUNCH = False
 
 
 def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, act=None, out=None,
@@ -650,7 +655,17 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
     else:
         sums = torch.empty(batch_size * C * 2, dtype=torch.float64, device=dev)
         call('ofx_gn_stats', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
-    # mean / rstd are derived from the sums inside the apply launch (ofx.h): no ofx_gn_finalize launch
+    # mean / rstd are derived from the sums inside the apply launch (ofx.h: no ofx_gn_finalize launch) -- except when
+    # the launch also writes the consuming GraphConv's aux rows: those blocks normalise scattered source rows of any
+    # batch element, one (batch, group) statistic per thread, and pay for deriving it themselves (measured at depth 6,
+    # C = 128: 75 us fused vs 61 us with the 4.7 us finalize launch; without aux rows the fused launch is as fast as the
+    # plain one: profiles/r03/gn_probe.txt).  GN_FINALIZE_LAUNCH = True forces the separate launch everywhere (A/B).
+    mean = rstd = None
+    if GN_FINALIZE_LAUNCH or (planes and aux_graph is not None):
+        mean = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
+        rstd = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
+        call('ofx_gn_finalize', ptr(sums), ptr(count), batch_size, C, groups, eps, count_eps, ptr(mean), ptr(rstd),
+             stream())
     w = weight.detach().reshape(-1)
     b = bias.detach().reshape(-1)
     if planes:
@@ -665,7 +680,7 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         if aux_graph is not None:
             seg_ptr, col, multi_seg, n_multi = aux_graph
             aux = torch.empty((n_multi + 1) * ldo, dtype=torch.uint8, device=dev)
-        call('ofx_gn_apply_planes', ptr(x), ldx, n, C, ptr(batch_id), None, None, ptr(sums), ptr(count), groups, eps,
+        call('ofx_gn_apply_planes', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(sums), ptr(count), groups, eps,
              count_eps, ptr(w), ptr(b), ACT[act], planes, ptr(out), ldo, ptr(seg_ptr), ptr(col), ptr(multi_seg), n_multi,
              ptr(aux), stream())
         setattr(out, PLANES_ATTR, planes)
@@ -676,7 +691,7 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         out = torch.empty(n, C, dtype=torch.float32, device=dev)
     out2, ldo = _row_major(out)
     assert out2 is out
-    call('ofx_gn_apply', ptr(x), ldx, n, C, ptr(batch_id), None, None, ptr(sums), ptr(count), groups, eps, count_eps,
+    call('ofx_gn_apply', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(sums), ptr(count), groups, eps, count_eps,
          ptr(w), ptr(b), ACT[act], ptr(out), ldo, stream())
     return out
 

@@ -28,6 +28,12 @@ for d, C in [(6, 128), (6, 256), (6, 384), (5, 256), (5, 512), (4, 512)]:
     t0 = timeit(lambda: f())
     t2 = timeit(lambda: f(planes=2))
     t2a = timeit(lambda: f(planes=2, aux_graph=(seg_ptr, col, multi_seg, V)))
+    # A/B: the separate ofx_gn_finalize launch (round 2) vs mean / rstd derived inside the apply launch (round 3)
+    ops.GN_FINALIZE_LAUNCH = True
+    t2a_sep = timeit(lambda: f(planes=2, aux_graph=(seg_ptr, col, multi_seg, V)))
+    t0_sep = timeit(lambda: f())
+    ops.GN_FINALIZE_LAUNCH = False
+    print('   finalize: fused %.1f / %.1f us (fp32 / planes+aux), separate launch %.1f / %.1f us' % (t0, t2a, t0_sep, t2a_sep))
     y = f(planes=2, aux_graph=(seg_ptr, col, multi_seg, V))
     aux_fold = getattr(y, ops.AUX_ATTR).clone()
     # stand-alone pre-pass on the planes for comparison (timed through a conv-less call of the kernel is not exposed;

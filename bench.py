@@ -579,6 +579,7 @@ def main():
                 # same kernels' data path, one tile per block (csrc/ofx_gemm2.hip) instead of persistent stream-K blocks
                 side('fp16x3_eager', 'fp16x3', True)
                 side('fp16x3_one_tile_per_block_launch', 'fp16x3', True, persistent=0)
+                side('fp16x3_pure_stream_k_launch', 'fp16x3', True, persistent=2)
                 side('bf16x3', 'bf16x3', True)
                 side('fp16x3_register_staged_kernel', 'fp16x3', False)
                 side('fp16_single_pass', 'fp16', True)

@@ -804,9 +804,11 @@ static int g3_auto_wm(int64_t M, int cout, int nkt, int ni) {
 int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, size_t ws_tail_bytes, void* sync,
                       size_t sync_bytes, hipStream_t st);
 static int g2_persistent = 1;               // 1 (default): persistent stream-K blocks where the shape qualifies
+void ofx_gconv3_set_hybrid(int on);          // ofx_gemm3.hip
 extern "C" int ofx_set_gconv_persistent(int on) {
-  if (on != 0 && on != 1) return OFX_EINVAL;
-  g2_persistent = on;
+  if (on < 0 || on > 2) return OFX_EINVAL;   // 2: persistent, pure stream-K (no whole-tile rounds) -- A/B
+  g2_persistent = on ? 1 : 0;
+  ofx_gconv3_set_hybrid(on == 2 ? 0 : 1);
   return OFX_OK;
 }
 

@@ -2,10 +2,16 @@
 //
 // Same data path as ofx_gemm2.hip (operand planes, LDS-DMA staging with a source-side swizzle, hand-counted waits,
 // bf16x3 / fp16 MFMA, two-phase epilogue) -- what changes is who computes what:
-//   * the launch is exactly as many blocks as the chip holds at once (G = CUs x blocks per CU); the k-steps of ALL
-//     tiles form one sequence of U = tiles x nkt units and block b owns the contiguous range [bound(b), bound(b+1))
-//     ("stream-K"): every block does the same amount of MFMA work whatever the tile count, so the 3.31 -> 4 round
-//     quantisation of the one-tile-per-block launch (17 % on the depth-6 128 -> 128 layer, 31 % on depth 5) is gone;
+//   * the launch is exactly as many blocks as the chip holds at once (G = CUs x blocks per CU).  Work = whole-tile
+//     ROUNDS + a stream-K REGION ("two-tile stream-K"): with T tiles, R = max(0, T / G - 1) rounds in which block lb
+//     takes tile r * G + lb -- the blocks of one XCD work on 32 ADJACENT tiles at the same time, so the column tiles
+//     of a row tile and the halo rows of Morton-neighbour tiles are shared through that XCD's L2 (with pure stream-K
+//     a block walked its tiles one after the other and every column tile re-streamed its rows from HBM: 3.4 GB per
+//     512 -> 512 launch against 1.1 GB, profiles/r03/pmc_traffic*.json) -- and the remaining G..2G tiles as ONE
+//     sequence of U = tiles x nkt k-step units of which block b owns the contiguous range [bound(b), bound(b+1)):
+//     every block does the same amount of MFMA work whatever the tile count, so the 3.31 -> 4 round quantisation of
+//     the one-tile-per-block launch (17 % on the depth-6 128 -> 128 layer, 31 % on depth 5) is gone.  The region is
+//     processed FIRST (its cut tiles are combined early), the rounds after it;
 //   * a block walks its range tile by tile WITHOUT leaving the k-loop pipeline: the neighbour-table slice of the next
 //     row tile is fetched by one LDS-DMA per wave at the start of the current tile and converted to line offsets
 //     inside the last steady k-step; the two drain k-steps of a tile -- which had nothing to request -- request the
@@ -40,8 +46,9 @@ template <int WM, int NI> struct G3Cfg : G2Cfg<WM, NI> {
 struct Gemm3Args {
   Gemm2Args b;
   int G;                       // blocks; a multiple of 8
-  unsigned q, rem;             // bound(lb) = lb * q + min(lb, rem), then snapped
-  unsigned U;                  // tiles * nkt
+  unsigned q, rem;             // stream-K region: bound(lb) = lb * q + min(lb, rem), then snapped
+  unsigned U;                  // units of the stream-K region (its tiles * nkt)
+  int dp_rounds;               // whole-tile rounds in front of it: tile r * G + lb belongs to block lb
   float* part;                 // [G][BM * BN] raw accumulator pieces
   unsigned* flags;             // [G + 1], zero on entry and on exit; flags[G] != 0: a spin gave up
   const char* nbr_lim;         // last 16-B aligned address inside nbr_ext that may be read
@@ -123,7 +130,10 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
   };
   unsigned u = (unsigned)sgpr32((int)bound(lb));
   const unsigned u_end = (unsigned)sgpr32((int)bound(lb + 1));
-  if (u >= u_end) return;                                    // (cannot happen for U / G >= 2 * G3_KMIN; kept for safety)
+  const int dp_rounds = A.dp_rounds;
+  const unsigned dp_tiles = (unsigned)dp_rounds * (unsigned)G;     // tiles [0, dp_tiles) are the rounds, the rest the region
+  int dp_r = 0;                                                    // next round of this block
+  if (u >= u_end && dp_rounds == 0) return;                  // (cannot happen for U / G >= 2 * G3_KMIN; kept for safety)
 
   // ---- per-lane DMA source state (as gconv2)
   const int q8 = lane & 7, rsub = lane >> 3;
@@ -341,8 +351,10 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
   };
 
   // ================================ block prologue: first piece ==============================================
-  unsigned t_cur = u / (unsigned)nkt;
-  int k0 = (int)(u - t_cur * (unsigned)nkt);
+  bool in_region = u < u_end;                                 // this piece is part of the stream-K region
+  unsigned t_cur = in_region ? dp_tiles + u / (unsigned)nkt : (unsigned)lb;
+  int k0 = in_region ? (int)(u % (unsigned)nkt) : 0;
+  if (!in_region) dp_r = 1;
   int tm = (int)(t_cur / (unsigned)ntn), tn = (int)t_cur - tm * ntn;
   int64_t m0 = a.row0 + (int64_t)tm * G2_BM, n0 = (int64_t)tn * G2_BN;
   raw_request(m0);
@@ -386,17 +398,27 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
 
   // ================================ piece loop ===============================================================
   for (;;) {
-    // this piece = k tiles [k0, k1) of tile t_cur
-    const unsigned left = u_end - u;
-    const int k1 = (unsigned)(nkt - k0) <= left ? nkt : k0 + (int)left;
+    // this piece = k tiles [k0, k1) of tile t_cur; the next one starts at k = 0 of: the following tile (inside the
+    // region), the block's first whole-tile round (after the region), its next round
+    int k1 = nkt;
+    bool has_next, next_in_region = false;
+    unsigned t_nxt;
+    if (in_region) {
+      const unsigned left = u_end - u;
+      k1 = (unsigned)(nkt - k0) <= left ? nkt : k0 + (int)left;
+      u += (unsigned)(k1 - k0);
+      next_in_region = u < u_end;
+      has_next = next_in_region || dp_rounds > 0;
+      t_nxt = next_in_region ? t_cur + 1 : (unsigned)lb;
+    } else {
+      has_next = dp_r < dp_rounds;
+      t_nxt = (unsigned)dp_r * (unsigned)G + (unsigned)lb;
+    }
     const int len = k1 - k0;
-    u += (unsigned)len;
-    const bool has_next = u < u_end;                                     // the next piece starts at k = 0 of tile t_cur + 1
-    const unsigned t_nxt = t_cur + 1;
     const int tm_n = (int)(t_nxt / (unsigned)ntn), tn_n = (int)t_nxt - tm_n * ntn;
     const int64_t m0_n = a.row0 + (int64_t)tm_n * G2_BM, n0_n = (int64_t)tn_n * G2_BN;
     const bool new_rows = has_next && tm_n != tm;
-    const bool finisher = k0 == 0;
+    const bool finisher = k0 == 0;                                       // (always, outside the region)
 
     const bool cut_head = finisher && k1 < nkt;                          // k tiles [k1, nkt) come from the next block(s)
 
@@ -570,7 +592,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
       if (cut_head && !early) {
         // small layers (several blocks per tile): the other pieces are computed at the same time as this one, so they
         // are added at the end, in ascending k order
-        const unsigned u_tile_end = (t_cur + 1) * (unsigned)nkt;
+        const unsigned u_tile_end = (t_cur - dp_tiles + 1) * (unsigned)nkt;    // (region units)
         int nc = 0;
         for (int c = lb + 1; c < G && bound(c) < u_tile_end; ++c) ++nc;
         wait_flags(nc);
@@ -638,6 +660,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
       ++dbg_piece;
     }
     if (!has_next) break;
+    if (!next_in_region) { in_region = false; ++dp_r; }
     t_cur = t_nxt; k0 = 0; tm = tm_n; tn = tn_n; m0 = m0_n; n0 = n0_n;
   }
 #undef G3_FENCE
@@ -678,22 +701,37 @@ static int g3_cus() {                  // compute units of the current device (c
 
 // Bytes of workspace the persistent launch needs behind the statistics partials (0: the shape is not eligible).
 // Launch plan: wm (2 / 4), ni (1 / 2) -> blocks G, units per block.
-struct G3Plan { int G; unsigned q, rem, U; size_t part_bytes; };
+struct G3Plan { int G; unsigned q, rem, U; int dp_rounds; size_t part_bytes; };
+static int g3_hybrid = 1;      // 1: whole-tile rounds + stream-K region; 0: pure stream-K (A/B, ofx_set_gconv_persistent(2))
 static bool g3_plan(int64_t M, int cout, int nkt, int wm, int ni, G3Plan& p) {
   const int cus = g3_cus();
   if (cus < 8 || nkt < G3_KMIN) return false;
   const int64_t tiles = ofx_cdiv(M, wm * 64) * ofx_cdiv(cout, 64 * ni);
-  const int64_t U = tiles * nkt;
-  if (U >= (1ll << 31)) return false;
-  int64_t slots = (int64_t)cus * (wm == 4 ? 1 : 2);
-  // shares of >= 2 * G3_KMIN units: after snapping every piece still has >= G3_KMIN k-steps
-  int64_t G = slots < U / (2 * G3_KMIN) ? slots : U / (2 * G3_KMIN);
-  G &= ~7ll;
+  if (tiles * nkt >= (1ll << 31)) return false;
+  int64_t slots = ((int64_t)cus * (wm == 4 ? 1 : 2)) & ~7ll;
+  int64_t G, region_tiles;
+  int rounds = 0;
+  if (tiles >= slots) {
+    // two-tile stream-K: the last (tiles mod G) + G tiles form the region, everything before it whole-tile rounds
+    G = slots;
+    rounds = g3_hybrid ? (int)(tiles / G - 1) : 0;
+    region_tiles = tiles - (int64_t)rounds * G;
+  } else {
+    // fewer tiles than block slots: the whole layer is the region, in shares of >= 2 * G3_KMIN units (after snapping
+    // every piece still has >= G3_KMIN k-steps)
+    const int64_t U = tiles * nkt;
+    G = slots < U / (2 * G3_KMIN) ? slots : U / (2 * G3_KMIN);
+    G &= ~7ll;
+    region_tiles = tiles;
+  }
   if (G < 8) return false;
-  p.G = (int)G; p.U = (unsigned)U; p.q = (unsigned)(U / G); p.rem = (unsigned)(U % G);
+  const int64_t U = region_tiles * nkt;
+  p.G = (int)G; p.U = (unsigned)U; p.q = (unsigned)(U / G); p.rem = (unsigned)(U % G); p.dp_rounds = rounds;
   p.part_bytes = (size_t)G * (size_t)(wm * 64) * (size_t)(64 * ni) * sizeof(float);
   return true;
 }
+
+void ofx_gconv3_set_hybrid(int on) { g3_hybrid = on ? 1 : 0; }
 
 // Called by ofx_graphconv_fwd_planes (ofx_gemm2.hip) once it has filled the common arguments.
 // Returns OFX_OK (launched), a failure status, or 1 when the shape / workspace does not qualify (caller falls back
@@ -711,9 +749,12 @@ int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, siz
   a.row0 = 0;
   g.ntm = (int)ofx_cdiv(g.M, wm * 64);
   A.b = a;
-  A.G = p.G; A.q = p.q; A.rem = p.rem; A.U = p.U;
+  A.G = p.G; A.q = p.q; A.rem = p.rem; A.U = p.U; A.dp_rounds = p.dp_rounds;
   A.part = (float*)ws_tail; A.flags = (unsigned*)sync;
-  A.early = p.q >= (unsigned)a.nkt + 2 * G3_KMIN ? 1 : 0;
+  // (shares of >= one tile: boundaries are >= nkt apart and snapping only ever moves one ONTO a tile boundary, so a
+  // tile has at most one interior cut; its second piece is its block's first work, published ~a tile before the
+  // finisher reaches its own)
+  A.early = p.q >= (unsigned)a.nkt ? 1 : 0;
   // last 16-B chunk that still starts inside the array (a chunk may run up to 12 B past the last entry: the caller
   // guarantees 16 B of readable slack behind nbr_ext, include/ofx.h)
   A.nbr_lim = (const char*)a.nbr_ext + ((((size_t)g.M * 28 - 4) >> 4) << 4);

@@ -142,3 +142,45 @@ def test_persistent_single_shape_and_ragged():
                     report(dict(test='persistent_small', case=name, depth=d, N=N, cin=cin, cout=cout, tile=tile, **e))
     finally:
         _lib.call('ofx_set_gconv2_tile', 0)
+
+
+def test_whole_tile_rounds_plus_region_at_bench_size():
+    """The launch shape of the bench workload itself (B = 8: 848 row tiles >= 2 x the block slots, so the launch has
+    whole-tile rounds in front of the stream-K region): persistent (rounds + region), persistent (pure stream-K) and
+    one-tile-per-block launches of the same layer agree, and the default one matches the fp64 oracle.  One layer with a
+    single column tile (halo sharing only) and one with four (the column tiles of a row tile run on one XCD together)."""
+    from octfusion_amd import _lib, modules as M, ops
+    from oracle import modules as OM
+    B = 8
+    oc, doc, o_oc, o_doc = shell6(B)
+    try:
+        for d, cin, cout in [(6, 128, 128), (5, 256, 512)]:
+            nt = d - 1
+            conv = M.GraphConv(cin, cout, 7, 7, nt)
+            gn = M.DualOctreeGroupNorm(cin)
+            sd = C.fill_state_dict([('c.' + k, tuple(v.shape)) for k, v in conv.state_dict().items()] +
+                                   [('g.' + k, tuple(v.shape)) for k, v in gn.state_dict().items()])
+            conv.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith('c.')})
+            gn.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith('g.')})
+            conv, gn = conv.to(dev()), gn.to(dev())
+            N = doc.csr(d)[2]
+            x = C.rand_input('pk8_x_%d_%d' % (d, cin), N, cin)
+            emb = C.rand_input('pk8_e_%d' % cout, B, cout)
+            res = C.rand_input('pk8_r_%d_%d' % (d, cout), N, cout)
+            h_ref = OM.silu(OM.dual_octree_group_norm(x.double(), o_doc, d, sd['g.weights'].double(), sd['g.bias'].double()))
+            ref = OM.graph_conv(h_ref, o_doc, d, sd['c.weights'].double(), None, nt) + emb.double()[o_doc.batch_id(d)] + res.double()
+            xg, eg, rg = x.to(dev()), emb.to(dev()), res.to(dev())
+            ys = {}
+            for pers in (0, 1, 2):
+                _lib.call('ofx_set_gconv_persistent', pers)
+                ys[pers], _ = _run(conv, gn, xg, doc, d, ops.planes_mode(), eg, rg, B * cout * 2)
+                torch.cuda.synchronize()
+                assert not ops.sync_error(dev())
+            e = errors(ys[1], ref)
+            assert e['rel_to_max'] < 2e-5, (d, cin, cout, e)
+            for pers in (1, 2):
+                cross = float((ys[pers] - ys[0]).abs().max() / ys[0].abs().max())
+                assert cross < 2e-6, (d, cin, cout, pers, cross)
+            report(dict(test='persistent_b8', depth=d, N=N, cin=cin, cout=cout, **e))
+    finally:
+        _lib.call('ofx_set_gconv_persistent', 1)

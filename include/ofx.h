@@ -391,7 +391,8 @@ int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int cin, int64_t
                              int64_t stats_ld, void* ws, size_t ws_bytes, void* sync /* optional */, size_t sync_bytes,
                              int mode, int aux_ready, void* stream);
 /* 1 (default): persistent launch (whole-tile rounds + a stream-K region) where the shape qualifies; 0: always one tile
- * per block; 2: persistent with pure stream-K (no whole-tile rounds) -- A/B knob */
+ * per block; 2: persistent with pure stream-K (no whole-tile rounds); 3: as 1 with share boundaries snapped towards the
+ * tile boundary instead of to the nearest legal cut -- A/B knobs, same values */
 int ofx_set_gconv_persistent(int on);
 /* scheduling variant of the one-tile-per-block planes kernel: 5 = LDS reads and DMA requests spliced between the
  * MFMAs -- the only one a product build contains (anything else: OFX_EINVAL).  Builds with -DOFX_ABLATION

@@ -805,10 +805,12 @@ int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, siz
                       size_t sync_bytes, hipStream_t st);
 static int g2_persistent = 1;               // 1 (default): persistent stream-K blocks where the shape qualifies
 void ofx_gconv3_set_hybrid(int on);          // ofx_gemm3.hip
+void ofx_gconv3_set_snap(int near);          // ofx_gemm3.hip
 extern "C" int ofx_set_gconv_persistent(int on) {
-  if (on < 0 || on > 2) return OFX_EINVAL;   // 2: persistent, pure stream-K (no whole-tile rounds) -- A/B
+  if (on < 0 || on > 3) return OFX_EINVAL;   // 2: pure stream-K (no whole-tile rounds), 3: round-1 share snapping -- A/B
   g2_persistent = on ? 1 : 0;
   ofx_gconv3_set_hybrid(on == 2 ? 0 : 1);
+  ofx_gconv3_set_snap(on == 3 ? 0 : 1);
   return OFX_OK;
 }
 

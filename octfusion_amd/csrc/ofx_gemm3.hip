@@ -52,6 +52,7 @@ struct Gemm3Args {
   float* part;                 // [G][BM * BN] raw accumulator pieces
   unsigned* flags;             // [G + 1], zero on entry and on exit; flags[G] != 0: a spin gave up
   const char* nbr_lim;         // last 16-B aligned address inside nbr_ext that may be read
+  int snap;                    // 1: share boundaries snapped to the nearest legal cut position, 0: towards the tile boundary (A/B)
   int early;                   // every share spans >= one tile (a tile is cut at most once, and its second piece is
                                // published before the finisher STARTS its own): the finisher starts from that piece
                                // instead of adding it at the end
@@ -121,14 +122,23 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
   float* const part_s = A.part;
   unsigned* const flags_s = A.flags;
   const int lb = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
+  const bool snap_near = A.snap != 0;
   auto bound = [&](int b) -> unsigned {
     unsigned u = (unsigned)b * sk_q + ((unsigned)b < sk_rem ? (unsigned)b : sk_rem);
     unsigned t = u / (unsigned)nkt, r = u - t * (unsigned)nkt;
-    if (r < (unsigned)G3_KMIN) r = 0;
-    else if (r + G3_KMIN > (unsigned)nkt) { r = 0; ++t; }
+    // a cut may sit at k = 0 or at G3_KMIN <= k <= nkt - G3_KMIN of a tile: snap to the NEAREST such position (snapping
+    // towards the tile boundary only, as the first version did, left shares of q - 7 .. q + 7 k-steps: with 30-step
+    // tiles that is +-7 % of a block's whole work, and every block of a persistent launch is on the critical path)
+    const bool mid = snap_near && (unsigned)nkt >= 2u * G3_KMIN;
+    if (r < (unsigned)G3_KMIN) r = (mid && 2u * r >= (unsigned)G3_KMIN) ? (unsigned)G3_KMIN : 0u;
+    else if (r + G3_KMIN > (unsigned)nkt) {
+      if (mid && r - ((unsigned)nkt - G3_KMIN) <= (unsigned)nkt - r) r = (unsigned)nkt - G3_KMIN;
+      else { r = 0; ++t; }
+    }
     return t * (unsigned)nkt + r;
   };
   unsigned u = (unsigned)sgpr32((int)bound(lb));
+  const unsigned u_begin = u;
   const unsigned u_end = (unsigned)sgpr32((int)bound(lb + 1));
   const int dp_rounds = A.dp_rounds;
   const unsigned dp_tiles = (unsigned)dp_rounds * (unsigned)G;     // tiles [0, dp_tiles) are the rounds, the rest the region
@@ -403,6 +413,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
     int k1 = nkt;
     bool has_next, next_in_region = false;
     unsigned t_nxt;
+    const unsigned u_before = u;
     if (in_region) {
       const unsigned left = u_end - u;
       k1 = (unsigned)(nkt - k0) <= left ? nkt : k0 + (int)left;
@@ -421,6 +432,11 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
     const bool finisher = k0 == 0;                                       // (always, outside the region)
 
     const bool cut_head = finisher && k1 < nkt;                          // k tiles [k1, nkt) come from the next block(s)
+    // start from the published piece only if it has (very probably) been published: its block started with it when
+    // this block started, so it is done once this block has worked through more k-steps than the piece is long.
+    // Otherwise add it at the end (decided from the schedule, not from the flag: the order of the additions -- and
+    // with it the last bits of the result -- must not depend on timing)
+    const bool early_now = early && (int)(u_before - u_begin) > nkt - k1;
 
     // batch element of this wave's first output row, for the time-embedding line of the epilogue requests (asked for
     // here so that its latency is this wait's, not the last k-steps')
@@ -438,7 +454,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
       if (threadIdx.x == 0) __hip_atomic_store(flags_s + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       flag_pending = false;
     }
-    if (cut_head && early) {
+    if (cut_head && early_now) {
       // start from the other piece of the tile (published long ago: it was its block's first work) instead of zero:
       // its 16 loads per lane go straight into the accumulators and fly together
       wait_flags(1);
@@ -589,7 +605,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
 
     // ---- the piece's result
     if (finisher) {
-      if (cut_head && !early) {
+      if (cut_head && !early_now) {
         // small layers (several blocks per tile): the other pieces are computed at the same time as this one, so they
         // are added at the end, in ascending k order
         const unsigned u_tile_end = (t_cur - dp_tiles + 1) * (unsigned)nkt;    // (region units)
@@ -702,6 +718,7 @@ static int g3_cus() {                  // compute units of the current device (c
 // Bytes of workspace the persistent launch needs behind the statistics partials (0: the shape is not eligible).
 // Launch plan: wm (2 / 4), ni (1 / 2) -> blocks G, units per block.
 struct G3Plan { int G; unsigned q, rem, U; int dp_rounds; size_t part_bytes; };
+static int g3_snap = 1;        // 1: nearest legal cut position; 0: towards the tile boundary (A/B, ofx_set_gconv_persistent(3))
 static int g3_hybrid = 1;      // 1: whole-tile rounds + stream-K region; 0: pure stream-K (A/B, ofx_set_gconv_persistent(2))
 static bool g3_plan(int64_t M, int cout, int nkt, int wm, int ni, G3Plan& p) {
   const int cus = g3_cus();
@@ -732,6 +749,7 @@ static bool g3_plan(int64_t M, int cout, int nkt, int wm, int ni, G3Plan& p) {
 }
 
 void ofx_gconv3_set_hybrid(int on) { g3_hybrid = on ? 1 : 0; }
+void ofx_gconv3_set_snap(int near) { g3_snap = near ? 1 : 0; }
 
 // Called by ofx_graphconv_fwd_planes (ofx_gemm2.hip) once it has filled the common arguments.
 // Returns OFX_OK (launched), a failure status, or 1 when the shape / workspace does not qualify (caller falls back
@@ -751,6 +769,7 @@ int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, siz
   A.b = a;
   A.G = p.G; A.q = p.q; A.rem = p.rem; A.U = p.U; A.dp_rounds = p.dp_rounds;
   A.part = (float*)ws_tail; A.flags = (unsigned*)sync;
+  A.snap = g3_snap;
   // (shares of >= one tile: boundaries are >= nkt apart and snapping only ever moves one ONTO a tile boundary, so a
   // tile has at most one interior cut; its second piece is its block's first work, published ~a tile before the
   // finisher reaches its own)

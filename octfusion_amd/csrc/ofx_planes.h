@@ -313,11 +313,34 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
   const int64_t tile_m = m0 / (WM * MI * 32);
   bool uni = true;
   int b0 = 0;
+  // A wave whose 64 rows lie in TWO batch elements (the tile holds a batch boundary: ~20 tiles per launch, but with
+  // persistent blocks every block is on the critical path): rows of the first element accumulate into one set of sums,
+  // the rest into a second, both are reduced like the uniform case and leave as ONE fp64 atomic pair per column and
+  // element.  (Until round 3 every lane flushed its own runs: ~2 000 contended atomics per wave, +30-40 k clocks for
+  // the block.)  maskA: bit i * 4 + G = this lane's row (i, G) belongs to the first element.  Three or more elements
+  // in one wave (a batch element with < 64 nodes at this depth) keep the per-lane path.
+  bool two = false;
+  int b1 = 0;
+  unsigned maskA = 0xffu;
   if (g.emb || g.stats) {
     // batch id of the wave's first row = lane 0's first row (reading it here, not in the request phase, keeps a
     // scalarised load + wait out of the k-loop's tail)
     b0 = __builtin_amdgcn_readfirstlane(P.bid);
     uni = __all(P.bid == b0);                               // (rows past the end read the last row's id)
+    if (!uni) {
+      b1 = __builtin_amdgcn_readlane(P.bid, 63);
+      two = __all(P.bid == b0 || P.bid == b1);
+      if (two) {
+        maskA = 0u;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int G = 0; G < 4; ++G) {
+            const int bb = __shfl(P.bid, i * 32 + q + 4 * h + 8 * G);          // lane r holds the id of row mw + r
+            maskA |= (bb == b0 ? 1u : 0u) << (i * 4 + G);
+          }
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -325,18 +348,23 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
     const bool ncol = n < g.N;
     const int64_t nc = ncol ? n : g.N - 4;
     g2_v4f euv = {0.f, 0.f, 0.f, 0.f};
-    if (g.emb && uni) euv = emb_in_bias ? P.bias[j] : *reinterpret_cast<const g2_v4f*>(g.emb + (int64_t)b0 * g.lde + nc);
+    if (g.emb && (uni || two))
+      euv = emb_in_bias ? P.bias[j] : *reinterpret_cast<const g2_v4f*>(g.emb + (int64_t)b0 * g.lde + nc);
     const float4 eu = make_float4(euv.x, euv.y, euv.z, euv.w);
+    float4 euB = f4zero();
+    if (g.emb && two) euB = *reinterpret_cast<const float4*>(g.emb + (int64_t)b1 * g.lde + nc);
     const float4 bv = g.bias ? make_float4(P.bias[j].x, P.bias[j].y, P.bias[j].z, P.bias[j].w) : f4zero();
     float4 ssum = f4zero(), ssq = f4zero();
+    float4 ssumB = f4zero(), ssqB = f4zero();
     int sb = -1;
-    auto flush = [&](int b) {
+    auto flush_to = [&](int b, const float4& s, const float4& sq) {
       double* o = g.stats + ((int64_t)b * g.stats_ld + n) * 2;
-      unsafeAtomicAdd(o + 0, (double)ssum.x); unsafeAtomicAdd(o + 1, (double)ssq.x);
-      unsafeAtomicAdd(o + 2, (double)ssum.y); unsafeAtomicAdd(o + 3, (double)ssq.y);
-      unsafeAtomicAdd(o + 4, (double)ssum.z); unsafeAtomicAdd(o + 5, (double)ssq.z);
-      unsafeAtomicAdd(o + 6, (double)ssum.w); unsafeAtomicAdd(o + 7, (double)ssq.w);
+      unsafeAtomicAdd(o + 0, (double)s.x); unsafeAtomicAdd(o + 1, (double)sq.x);
+      unsafeAtomicAdd(o + 2, (double)s.y); unsafeAtomicAdd(o + 3, (double)sq.y);
+      unsafeAtomicAdd(o + 4, (double)s.z); unsafeAtomicAdd(o + 5, (double)sq.z);
+      unsafeAtomicAdd(o + 6, (double)s.w); unsafeAtomicAdd(o + 7, (double)sq.w);
     };
+    auto flush = [&](int b) { flush_to(b, ssum, ssq); };
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       float4 t[4];
@@ -351,20 +379,31 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
         const int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
         if (m >= g.M || !ncol) continue;
         float4 v = t[G];
+        const bool inA = (maskA >> (i * 4 + G)) & 1u;       // (uniform wave: all ones)
         if (g.emb) {
-          if (uni) f4add(v, eu);
-          else f4add(v, *reinterpret_cast<const float4*>(g.emb + (int64_t)g.bid[m] * g.lde + n));   // (a wave across two batch elements: rare)
+          if (uni || two) f4add(v, inA ? eu : euB);
+          else f4add(v, *reinterpret_cast<const float4*>(g.emb + (int64_t)g.bid[m] * g.lde + n));   // (>= 3 elements in one wave)
         }
         if (g.res) f4add(v, make_float4(P.res[i][j][G].x, P.res[i][j][G].y, P.res[i][j][G].z, P.res[i][j][G].w));
         if (g.stats) {
-          const int b = uni ? b0 : g.bid[m];
-          if (!uni && b != sb) {
-            if (sb >= 0) flush(sb);
-            ssum = f4zero(); ssq = f4zero();
+          if (uni || two) {
+            if (inA) {
+              f4add(ssum, v);
+              ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
+            } else {
+              f4add(ssumB, v);
+              ssqB.x += v.x * v.x; ssqB.y += v.y * v.y; ssqB.z += v.z * v.z; ssqB.w += v.w * v.w;
+            }
+          } else {
+            const int b = g.bid[m];
+            if (b != sb) {
+              if (sb >= 0) flush(sb);
+              ssum = f4zero(); ssq = f4zero();
+            }
+            sb = b;
+            f4add(ssum, v);
+            ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
           }
-          sb = b;
-          f4add(ssum, v);
-          ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
         }
         *reinterpret_cast<float4*>(g.out + m * g.ldc + n) = v;
       }
@@ -385,7 +424,20 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
           }
         }
       } else {
-        if (sb >= 0 && ncol) flush(sb);
+        if (two) {
+#define OFX_RED(f) f += dpp_xor1(f); f += dpp_xor2(f); f += __shfl_xor(f, 32);
+          OFX_RED(ssum.x) OFX_RED(ssum.y) OFX_RED(ssum.z) OFX_RED(ssum.w)
+          OFX_RED(ssq.x) OFX_RED(ssq.y) OFX_RED(ssq.z) OFX_RED(ssq.w)
+          OFX_RED(ssumB.x) OFX_RED(ssumB.y) OFX_RED(ssumB.z) OFX_RED(ssumB.w)
+          OFX_RED(ssqB.x) OFX_RED(ssqB.y) OFX_RED(ssqB.z) OFX_RED(ssqB.w)
+#undef OFX_RED
+          if (q == 0 && h == 0 && ncol && mw < g.M) {
+            flush_to(b0, ssum, ssq);
+            flush_to(b1, ssumB, ssqB);
+          }
+        } else if (sb >= 0 && ncol) {
+          flush(sb);
+        }
         if (g.stats_part && q == 0 && h == 0 && ncol && mw < g.M) {      // mixed wave: its slot must read as zero
           float* o = g.stats_part + ((tile_m * WM + wm) * g.N + n) * 2;
           *reinterpret_cast<float4*>(o) = f4zero();

@@ -70,7 +70,7 @@ for d, cin, cout, cnt in shapes:
     flops = 2.0 * N * 7 * (cin + d - 1) * cout
     out = dict(d=d, N=N, cin=cin, cout=cout, launches_per_step=cnt)
     ys = {}
-    for name, pers, tile in (('tile', 0, 0), ('pk2', 2, 2), ('pk4', 2, 4), ('hy4', 1, 4)):       # pk*: pure stream-K; hy4: rounds + region
+    for name, pers, tile in (('tile', 0, 0), ('pk2', 2, 2), ('pk4', 2, 4), ('hy4f', 3, 4), ('hy4', 1, 4)):       # pk*: pure stream-K; hy4: rounds + region (hy4f: round-1 share snapping)
         _lib.call('ofx_set_gconv_persistent', pers)
         _lib.call('ofx_set_gconv2_tile', tile)
 
@@ -85,6 +85,7 @@ for d, cin, cout, cnt in shapes:
     out['pk2_vs_tile'] = float((ys['pk2'] - ys['tile']).abs().max() / ys['tile'].abs().max())
     out['pk4_vs_tile'] = float((ys['pk4'] - ys['tile']).abs().max() / ys['tile'].abs().max())
     out['hy4_vs_tile'] = float((ys['hy4'] - ys['tile']).abs().max() / ys['tile'].abs().max())
+    out['hy4f_vs_tile'] = float((ys['hy4f'] - ys['tile']).abs().max() / ys['tile'].abs().max())
     torch.cuda.synchronize()
     out['sync_error'] = ops.sync_error(dev)
     rows.append(out)
@@ -92,7 +93,7 @@ for d, cin, cout, cnt in shapes:
     sys.stdout.flush()
 _lib.call('ofx_set_gconv_persistent', 1)
 _lib.call('ofx_set_gconv2_tile', 0)
-best = sum(min(r['tile_us'], r['pk2_us'], r['pk4_us'], r['hy4_us']) * r['launches_per_step'] for r in rows)
+best = sum(min(r['tile_us'], r['pk2_us'], r['pk4_us'], r['hy4_us'], r['hy4f_us']) * r['launches_per_step'] for r in rows)
 print(json.dumps(dict(summary='us per step over the listed launches', **tot, best_per_layer=best)))
 if args.json:
     json.dump(dict(rows=rows, totals=tot, best_per_layer=best), open(args.json, 'w'), indent=1)

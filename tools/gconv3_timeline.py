@@ -44,6 +44,10 @@ for (d, cin, cout, epi) in SHAPES:
         e1.record()
         torch.cuda.synchronize()
         _lib.call('ofx_set_gconv2_debug', None)
+        if os.environ.get('G3_RAW'):
+            os.makedirs(os.environ['G3_RAW'], exist_ok=True)
+            torch.save(dict(stamps=buf.view(nblk, 16).cpu(), d=d, cin=cin, cout=cout, epi=epi, tile=tile),
+                       os.path.join(os.environ['G3_RAW'], 'stamps_d%d_%d_%d_%d_t%d.pt' % (d, cin, cout, int(epi), tile)))
         t = buf.view(nblk, 16).cpu().double()
         t = t[t[:, 0] > 0]
         G = t.shape[0]

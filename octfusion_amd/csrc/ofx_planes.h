@@ -342,51 +342,68 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
       }
     }
   }
+  auto flush_to = [&](int b, int64_t n, const float4& s, const float4& sq) {
+    double* o = g.stats + ((int64_t)b * g.stats_ld + n) * 2;
+    unsafeAtomicAdd(o + 0, (double)s.x); unsafeAtomicAdd(o + 1, (double)sq.x);
+    unsafeAtomicAdd(o + 2, (double)s.y); unsafeAtomicAdd(o + 3, (double)sq.y);
+    unsafeAtomicAdd(o + 4, (double)s.z); unsafeAtomicAdd(o + 5, (double)sq.z);
+    unsafeAtomicAdd(o + 6, (double)s.w); unsafeAtomicAdd(o + 7, (double)sq.w);
+  };
+#define OFX_RED(f) f += dpp_xor1(f); f += dpp_xor2(f); f += __shfl_xor(f, 32);
+  if (uni || two) {
+    // ---- the path every tile but a handful takes.  NO load inside the store loops: on gfx9 stores count in vmcnt,
+    // and a compiler-visible load anywhere between them makes hipcc wait for vmcnt(0) -- i.e. for the previous STORE to
+    // be acknowledged -- before every row (the generic path below used to be interleaved with this one: 16 serialised
+    // store round trips per wave, 7-12 k clocks per tile with the matrix pipe idle)
+    // The two embedding rows a wave may need are asked for by inline asm and waited for by hand, only when something
+    // was asked for: a compiler-visible load here would put a conservative vmcnt(0) on the common path too -- and that
+    // is a wait for the NEXT tile's first DMA, which the persistent kernel has in flight by now.
+    g2_v4f euA[NI], euBv[NI];
+    const bool ask_a = g.emb && !emb_in_bias, ask_b = g.emb && two;
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
-    const bool ncol = n < g.N;
-    const int64_t nc = ncol ? n : g.N - 4;
-    g2_v4f euv = {0.f, 0.f, 0.f, 0.f};
-    if (g.emb && (uni || two))
-      euv = emb_in_bias ? P.bias[j] : *reinterpret_cast<const g2_v4f*>(g.emb + (int64_t)b0 * g.lde + nc);
-    const float4 eu = make_float4(euv.x, euv.y, euv.z, euv.w);
-    float4 euB = f4zero();
-    if (g.emb && two) euB = *reinterpret_cast<const float4*>(g.emb + (int64_t)b1 * g.lde + nc);
-    const float4 bv = g.bias ? make_float4(P.bias[j].x, P.bias[j].y, P.bias[j].z, P.bias[j].w) : f4zero();
-    float4 ssum = f4zero(), ssq = f4zero();
-    float4 ssumB = f4zero(), ssqB = f4zero();
-    int sb = -1;
-    auto flush_to = [&](int b, const float4& s, const float4& sq) {
-      double* o = g.stats + ((int64_t)b * g.stats_ld + n) * 2;
-      unsafeAtomicAdd(o + 0, (double)s.x); unsafeAtomicAdd(o + 1, (double)sq.x);
-      unsafeAtomicAdd(o + 2, (double)s.y); unsafeAtomicAdd(o + 3, (double)sq.y);
-      unsafeAtomicAdd(o + 4, (double)s.z); unsafeAtomicAdd(o + 5, (double)sq.z);
-      unsafeAtomicAdd(o + 6, (double)s.w); unsafeAtomicAdd(o + 7, (double)sq.w);
-    };
-    auto flush = [&](int b) { flush_to(b, ssum, ssq); };
+    for (int j = 0; j < NI; ++j) {
+      int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
+      n = n < g.N ? n : g.N - 4;
+      euA[j] = g2_v4f{0.f, 0.f, 0.f, 0.f};
+      euBv[j] = g2_v4f{0.f, 0.f, 0.f, 0.f};
+      if (g.emb && emb_in_bias) euA[j] = P.bias[j];
+      if (ask_a) g2_req128(euA[j], g.emb + (int64_t)b0 * g.lde + n);
+      if (ask_b) g2_req128(euBv[j], g.emb + (int64_t)b1 * g.lde + n);
+    }
+    if (ask_a || ask_b) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      float4 t[4];
+      for (int j = 0; j < NI; ++j)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(euA[j]), "+v"(euBv[j])::"memory");
+    }
+    float4 euB[NI];
 #pragma unroll
-      for (int G = 0; G < 4; ++G) {                         // every lane takes part in the transposes
-        float v0 = acc[i][j][4 * G], v1 = acc[i][j][4 * G + 1], v2 = acc[i][j][4 * G + 2], v3 = acc[i][j][4 * G + 3];
-        quad_transpose(v0, v1, v2, v3, q0, q1);
-        t[G] = make_float4(v0 + bv.x, v1 + bv.y, v2 + bv.z, v3 + bv.w);
-      }
+    for (int j = 0; j < NI; ++j) euB[j] = make_float4(euBv[j].x, euBv[j].y, euBv[j].z, euBv[j].w);
 #pragma unroll
-      for (int G = 0; G < 4; ++G) {
-        const int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
-        if (m >= g.M || !ncol) continue;
-        float4 v = t[G];
-        const bool inA = (maskA >> (i * 4 + G)) & 1u;       // (uniform wave: all ones)
-        if (g.emb) {
-          if (uni || two) f4add(v, inA ? eu : euB);
-          else f4add(v, *reinterpret_cast<const float4*>(g.emb + (int64_t)g.bid[m] * g.lde + n));   // (>= 3 elements in one wave)
+    for (int j = 0; j < NI; ++j) {
+      const int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
+      const bool ncol = n < g.N;
+      const float4 eu = make_float4(euA[j].x, euA[j].y, euA[j].z, euA[j].w);
+      const float4 bv = g.bias ? make_float4(P.bias[j].x, P.bias[j].y, P.bias[j].z, P.bias[j].w) : f4zero();
+      float4 ssum = f4zero(), ssq = f4zero();
+      float4 ssumB = f4zero(), ssqB = f4zero();
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        float4 t[4];
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {                         // every lane takes part in the transposes
+          float v0 = acc[i][j][4 * G], v1 = acc[i][j][4 * G + 1], v2 = acc[i][j][4 * G + 2], v3 = acc[i][j][4 * G + 3];
+          quad_transpose(v0, v1, v2, v3, q0, q1);
+          t[G] = make_float4(v0 + bv.x, v1 + bv.y, v2 + bv.z, v3 + bv.w);
         }
-        if (g.res) f4add(v, make_float4(P.res[i][j][G].x, P.res[i][j][G].y, P.res[i][j][G].z, P.res[i][j][G].w));
-        if (g.stats) {
-          if (uni || two) {
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+          const int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
+          if (m >= g.M || !ncol) continue;
+          float4 v = t[G];
+          const bool inA = (maskA >> (i * 4 + G)) & 1u;       // (uniform wave: all ones)
+          if (g.emb) f4add(v, inA ? eu : euB[j]);
+          if (g.res) f4add(v, make_float4(P.res[i][j][G].x, P.res[i][j][G].y, P.res[i][j][G].z, P.res[i][j][G].w));
+          if (g.stats) {
             if (inA) {
               f4add(ssum, v);
               ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
@@ -394,50 +411,74 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
               f4add(ssumB, v);
               ssqB.x += v.x * v.x; ssqB.y += v.y * v.y; ssqB.z += v.z * v.z; ssqB.w += v.w * v.w;
             }
+          }
+          *reinterpret_cast<float4*>(g.out + m * g.ldc + n) = v;
+        }
+      }
+      if (g.stats) {
+        OFX_RED(ssum.x) OFX_RED(ssum.y) OFX_RED(ssum.z) OFX_RED(ssum.w)
+        OFX_RED(ssq.x) OFX_RED(ssq.y) OFX_RED(ssq.z) OFX_RED(ssq.w)
+        if (two) {
+          OFX_RED(ssumB.x) OFX_RED(ssumB.y) OFX_RED(ssumB.z) OFX_RED(ssumB.w)
+          OFX_RED(ssqB.x) OFX_RED(ssqB.y) OFX_RED(ssqB.z) OFX_RED(ssqB.w)
+        }
+        if (q == 0 && h == 0 && ncol && mw < g.M) {
+          float* o = g.stats_part ? g.stats_part + ((tile_m * WM + wm) * g.N + n) * 2 : nullptr;
+          if (uni && o) {
+            *reinterpret_cast<float4*>(o) = make_float4(ssum.x, ssq.x, ssum.y, ssq.y);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(ssum.z, ssq.z, ssum.w, ssq.w);
           } else {
-            const int b = g.bid[m];
+            flush_to(b0, n, ssum, ssq);
+            if (two) flush_to(b1, n, ssumB, ssqB);
+            if (o) {                                          // mixed wave: its slot must read as zero
+              *reinterpret_cast<float4*>(o) = f4zero();
+              *reinterpret_cast<float4*>(o + 4) = f4zero();
+            }
+          }
+        }
+      }
+    }
+  } else {
+    // ---- three or more batch elements inside one 64-row wave (an element with < 64 nodes at this depth): per-row
+    // batch ids, every lane flushes its own runs
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
+      const bool ncol = n < g.N;
+      const float4 bv = g.bias ? make_float4(P.bias[j].x, P.bias[j].y, P.bias[j].z, P.bias[j].w) : f4zero();
+      float4 ssum = f4zero(), ssq = f4zero();
+      int sb = -1;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        float4 t[4];
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+          float v0 = acc[i][j][4 * G], v1 = acc[i][j][4 * G + 1], v2 = acc[i][j][4 * G + 2], v3 = acc[i][j][4 * G + 3];
+          quad_transpose(v0, v1, v2, v3, q0, q1);
+          t[G] = make_float4(v0 + bv.x, v1 + bv.y, v2 + bv.z, v3 + bv.w);
+        }
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+          const int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
+          if (m >= g.M || !ncol) continue;
+          float4 v = t[G];
+          const int b = g.bid[m];
+          if (g.emb) f4add(v, *reinterpret_cast<const float4*>(g.emb + (int64_t)b * g.lde + n));
+          if (g.res) f4add(v, make_float4(P.res[i][j][G].x, P.res[i][j][G].y, P.res[i][j][G].z, P.res[i][j][G].w));
+          if (g.stats) {
             if (b != sb) {
-              if (sb >= 0) flush(sb);
+              if (sb >= 0) flush_to(sb, n, ssum, ssq);
               ssum = f4zero(); ssq = f4zero();
             }
             sb = b;
             f4add(ssum, v);
             ssq.x += v.x * v.x; ssq.y += v.y * v.y; ssq.z += v.z * v.z; ssq.w += v.w * v.w;
           }
+          *reinterpret_cast<float4*>(g.out + m * g.ldc + n) = v;
         }
-        *reinterpret_cast<float4*>(g.out + m * g.ldc + n) = v;
       }
-    }
-    if (g.stats) {
-      if (uni) {
-#define OFX_RED(f) f += dpp_xor1(f); f += dpp_xor2(f); f += __shfl_xor(f, 32);
-        OFX_RED(ssum.x) OFX_RED(ssum.y) OFX_RED(ssum.z) OFX_RED(ssum.w)
-        OFX_RED(ssq.x) OFX_RED(ssq.y) OFX_RED(ssq.z) OFX_RED(ssq.w)
-#undef OFX_RED
-        if (q == 0 && h == 0 && ncol && mw < g.M) {
-          if (g.stats_part) {
-            float* o = g.stats_part + ((tile_m * WM + wm) * g.N + n) * 2;
-            *reinterpret_cast<float4*>(o) = make_float4(ssum.x, ssq.x, ssum.y, ssq.y);
-            *reinterpret_cast<float4*>(o + 4) = make_float4(ssum.z, ssq.z, ssum.w, ssq.w);
-          } else {
-            flush(b0);
-          }
-        }
-      } else {
-        if (two) {
-#define OFX_RED(f) f += dpp_xor1(f); f += dpp_xor2(f); f += __shfl_xor(f, 32);
-          OFX_RED(ssum.x) OFX_RED(ssum.y) OFX_RED(ssum.z) OFX_RED(ssum.w)
-          OFX_RED(ssq.x) OFX_RED(ssq.y) OFX_RED(ssq.z) OFX_RED(ssq.w)
-          OFX_RED(ssumB.x) OFX_RED(ssumB.y) OFX_RED(ssumB.z) OFX_RED(ssumB.w)
-          OFX_RED(ssqB.x) OFX_RED(ssqB.y) OFX_RED(ssqB.z) OFX_RED(ssqB.w)
-#undef OFX_RED
-          if (q == 0 && h == 0 && ncol && mw < g.M) {
-            flush_to(b0, ssum, ssq);
-            flush_to(b1, ssumB, ssqB);
-          }
-        } else if (sb >= 0 && ncol) {
-          flush(sb);
-        }
+      if (g.stats) {
+        if (sb >= 0 && ncol) flush_to(sb, n, ssum, ssq);
         if (g.stats_part && q == 0 && h == 0 && ncol && mw < g.M) {      // mixed wave: its slot must read as zero
           float* o = g.stats_part + ((tile_m * WM + wm) * g.N + n) * 2;
           *reinterpret_cast<float4*>(o) = f4zero();
@@ -446,4 +487,5 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
       }
     }
   }
+#undef OFX_RED
 }

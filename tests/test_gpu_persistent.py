@@ -184,3 +184,66 @@ def test_whole_tile_rounds_plus_region_at_bench_size():
             report(dict(test='persistent_b8', depth=d, N=N, cin=cin, cout=cout, **e))
     finally:
         _lib.call('ofx_set_gconv_persistent', 1)
+
+
+@pytest.mark.parametrize('persistent', [1, 0])
+def test_epilogue_batch_labels_inside_one_wave(persistent):
+    """The three epilogue paths of the planes GraphConv by the number of batch elements inside one 64-row wave:
+    one (per-wave partial sums -> second-stage reduce), two (two sets of sums, one atomic pair per column and
+    element), three or more (per-lane runs) -- an element with fewer than 64 nodes at a depth, which no synthetic tree of
+    the suite has.  The kernel only reads the labels, so they are planted: a real depth-6 layer, its time-embedding add
+    and fused GroupNorm sums checked against the same output relabelled on the host."""
+    from octfusion_amd import _lib, modules as M, ops
+    B, d, cin, cout, mode = 6, 6, 128, 128, 3
+    oc, doc, _, _ = shell6(2)
+    saved = ops.get_precision()
+    ops.set_precision('fp16x3')
+    try:
+        conv = M.GraphConv(cin, cout, 7, 7, d - 1)
+        gn = M.DualOctreeGroupNorm(cin)
+        sd = C.fill_state_dict([('c.' + k, tuple(v.shape)) for k, v in conv.state_dict().items()] +
+                               [('g.' + k, tuple(v.shape)) for k, v in gn.state_dict().items()])
+        conv.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith('c.')})
+        gn.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith('g.')})
+        conv, gn = conv.to(dev()), gn.to(dev())
+        N = doc.csr(d)[2]
+        x = C.rand_input('lab_x', N, cin).to(dev())
+        emb = C.rand_input('lab_e', B, cout).to(dev())
+        res = C.rand_input('lab_r', N, cout).to(dev())
+        # labels 0..5 in ascending runs: a 10-row element inside one wave (three labels in that wave), a boundary in
+        # the middle of a wave (two labels), a boundary on a wave boundary, one on a tile boundary, a 3-row tail
+        cuts = [0, 1000, 1010, 5 * 256 + 64, 40 * 256, N - 3, N]
+        bid = torch.zeros(N, dtype=torch.int32)
+        for b in range(B):
+            bid[cuts[b]:cuts[b + 1]] = b
+        bid = bid.to(dev())
+        hp = gn(x, doc, d, act='silu', planes=mode)
+        nt = d - 1
+        pw2 = conv._pw2.get(conv.weights, cin, nt, mode)
+        seg_ptr, col, _, _ = doc.csr(d)
+        _lib.call('ofx_set_gconv_persistent', persistent)
+        base = None
+        for tile in (2, 4):
+            _lib.call('ofx_set_gconv2_tile', tile)
+            with ops.stats_scope(dev()):
+                y0 = ops.graphconv_planes(hp, mode, seg_ptr, col, doc.ext(d), pw2, cin, nt, doc.type_frac_planes(d, nt, mode),
+                                          None, None, bid, res, None, stats=None).clone()      # no labels involved
+                stats = ops.stats_zeros(B * cout * 2, dev())
+                y = ops.graphconv_planes(hp, mode, seg_ptr, col, doc.ext(d), pw2, cin, nt, doc.type_frac_planes(d, nt, mode),
+                                         None, emb, bid, res, None, stats=stats).clone()
+                st = stats.clone()
+            torch.cuda.synchronize()
+            want = y0 + emb[bid.long()]
+            assert float((y - want).abs().max()) <= 1e-6 * float(want.abs().max())
+            ws = torch.zeros(B, cout, 2, dtype=torch.float64, device=dev())
+            ws[:, :, 0].index_add_(0, bid.long(), y.double())
+            ws[:, :, 1].index_add_(0, bid.long(), y.double() ** 2)
+            assert float((st.view(B, cout, 2) - ws).abs().max()) <= 1e-5 * float(ws.abs().max())
+            if base is not None and not persistent:
+                assert torch.equal(y, base)
+            base = y
+            assert not ops.sync_error(dev())
+    finally:
+        _lib.call('ofx_set_gconv_persistent', 1)
+        _lib.call('ofx_set_gconv2_tile', 0)
+        ops.set_precision(saved)

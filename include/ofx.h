@@ -394,6 +394,11 @@ int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int cin, int64_t
  * per block; 2: persistent with pure stream-K (no whole-tile rounds); 3: as 1 with share boundaries snapped towards the
  * tile boundary instead of to the nearest legal cut -- A/B knobs, same values */
 int ofx_set_gconv_persistent(int on);
+/* The schedule ofx_graphconv_fwd_planes' persistent launch would use for n_rows x cout outputs and nkt k-steps per tile
+ * (host only, no device work; cus > 0: plan for that many compute units): out[0..4] = blocks G, q, rem, region units U,
+ * whole-tile rounds; out[5 .. 5 + G] = share boundaries of the stream-K region (k-step units, bound(0) = 0,
+ * bound(G) = U; every piece between a boundary and a tile edge has >= 8 k-steps).  Returns G, 0 = not eligible. */
+int ofx_gconv3_plan(int64_t n_rows, int cout, int nkt, int wm, int ni, int cus, int32_t* out, int64_t out_len);
 /* scheduling variant of the one-tile-per-block planes kernel: 5 = LDS reads and DMA requests spliced between the
  * MFMAs -- the only one a product build contains (anything else: OFX_EINVAL).  Builds with -DOFX_ABLATION
  * (python -m octfusion_amd.build --ablation) also hold 1 = DMA requests interleaved by sched_group_barrier,

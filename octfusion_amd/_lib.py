@@ -108,6 +108,7 @@ _SIGS = {
                                        c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_sz, c_p, c_sz, c_i, c_i,
                                        c_p], True),
     'ofx_set_gconv_persistent': (c_i, [c_i], True),
+    'ofx_gconv3_plan': (c_i, [c_l, c_i, c_i, c_i, c_i, c_i, c_p, c_l], False),
     'ofx_set_gconv2_variant': (c_i, [c_i], True),
     'ofx_set_gconv2_debug': (c_i, [c_p], True),
     'ofx_set_gconv2_tile': (c_i, [c_i], True),

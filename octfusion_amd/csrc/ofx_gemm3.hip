@@ -64,6 +64,22 @@ __device__ __forceinline__ void g3_ds_write32(unsigned addr, unsigned v) {
 __device__ __forceinline__ void g3_store128_sc1(void* p, g2_v4f v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
+// Share boundary of block b in the stream-K region (k-step units): the even split b * q + min(b, rem), moved to the
+// nearest position a cut may sit at -- k = 0 or G3_KMIN <= k <= nkt - G3_KMIN of a tile (every piece then has the
+// loop shape the kernel is written for).  `near` = 0: the first version's rule, towards the tile boundary only (shares
+// of q - 7 .. q + 7 k-steps: with 30-step tiles +-7 % of a block's whole work, and every block of a persistent launch
+// is on the critical path).  Host and device agree by construction (ofx_gconv3_plan, tests/test_abi.py).
+__host__ __device__ inline unsigned g3_bound(unsigned b, unsigned q, unsigned rem, unsigned nkt, bool near) {
+  unsigned u = b * q + (b < rem ? b : rem);
+  unsigned t = u / nkt, r = u - t * nkt;
+  const bool mid = near && nkt >= 2u * G3_KMIN;
+  if (r < (unsigned)G3_KMIN) r = (mid && 2u * r >= (unsigned)G3_KMIN) ? (unsigned)G3_KMIN : 0u;
+  else if (r + G3_KMIN > nkt) {
+    if (mid && r - (nkt - G3_KMIN) <= nkt - r) r = nkt - G3_KMIN;
+    else { r = 0; ++t; }
+  }
+  return t * nkt + r;
+}
 struct G3Raw { uint32_t v[4]; };
 __device__ __forceinline__ void g3_wait_lgkm0(G3Raw& R) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.v[0]), "+v"(R.v[1]), "+v"(R.v[2]), "+v"(R.v[3])::"memory");
@@ -123,20 +139,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
   unsigned* const flags_s = A.flags;
   const int lb = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
   const bool snap_near = A.snap != 0;
-  auto bound = [&](int b) -> unsigned {
-    unsigned u = (unsigned)b * sk_q + ((unsigned)b < sk_rem ? (unsigned)b : sk_rem);
-    unsigned t = u / (unsigned)nkt, r = u - t * (unsigned)nkt;
-    // a cut may sit at k = 0 or at G3_KMIN <= k <= nkt - G3_KMIN of a tile: snap to the NEAREST such position (snapping
-    // towards the tile boundary only, as the first version did, left shares of q - 7 .. q + 7 k-steps: with 30-step
-    // tiles that is +-7 % of a block's whole work, and every block of a persistent launch is on the critical path)
-    const bool mid = snap_near && (unsigned)nkt >= 2u * G3_KMIN;
-    if (r < (unsigned)G3_KMIN) r = (mid && 2u * r >= (unsigned)G3_KMIN) ? (unsigned)G3_KMIN : 0u;
-    else if (r + G3_KMIN > (unsigned)nkt) {
-      if (mid && r - ((unsigned)nkt - G3_KMIN) <= (unsigned)nkt - r) r = (unsigned)nkt - G3_KMIN;
-      else { r = 0; ++t; }
-    }
-    return t * (unsigned)nkt + r;
-  };
+  auto bound = [&](int b) -> unsigned { return g3_bound((unsigned)b, sk_q, sk_rem, (unsigned)nkt, snap_near); };
   unsigned u = (unsigned)sgpr32((int)bound(lb));
   const unsigned u_begin = u;
   const unsigned u_end = (unsigned)sgpr32((int)bound(lb + 1));
@@ -720,8 +723,8 @@ static int g3_cus() {                  // compute units of the current device (c
 struct G3Plan { int G; unsigned q, rem, U; int dp_rounds; size_t part_bytes; };
 static int g3_snap = 1;        // 1: nearest legal cut position; 0: towards the tile boundary (A/B, ofx_set_gconv_persistent(3))
 static int g3_hybrid = 1;      // 1: whole-tile rounds + stream-K region; 0: pure stream-K (A/B, ofx_set_gconv_persistent(2))
-static bool g3_plan(int64_t M, int cout, int nkt, int wm, int ni, G3Plan& p) {
-  const int cus = g3_cus();
+static bool g3_plan(int64_t M, int cout, int nkt, int wm, int ni, G3Plan& p, int cus = 0) {
+  if (cus <= 0) cus = g3_cus();
   if (cus < 8 || nkt < G3_KMIN) return false;
   const int64_t tiles = ofx_cdiv(M, wm * 64) * ofx_cdiv(cout, 64 * ni);
   if (tiles * nkt >= (1ll << 31)) return false;
@@ -750,6 +753,22 @@ static bool g3_plan(int64_t M, int cout, int nkt, int wm, int ni, G3Plan& p) {
 
 void ofx_gconv3_set_hybrid(int on) { g3_hybrid = on ? 1 : 0; }
 void ofx_gconv3_set_snap(int near) { g3_snap = near ? 1 : 0; }
+
+// The schedule of a persistent launch, on the host (no device work; `cus` > 0: plan for that many compute units
+// without asking a device): out[0..4] = blocks G, q, rem, region units U, whole-tile rounds; out[5 .. 5 + G] = the
+// region's share boundaries bound(0..G) as the kernel computes them.  Returns G, or 0 when the shape does not
+// qualify for the persistent launch (then nothing is written).  include/ofx.h.
+extern "C" int ofx_gconv3_plan(int64_t n_rows, int cout, int nkt, int wm, int ni, int cus, int32_t* out, int64_t out_len) {
+  G3Plan p;
+  if (n_rows <= 0 || cout <= 0 || nkt <= 0 || (wm != 2 && wm != 4) || (ni != 1 && ni != 2)) return 0;
+  if (!g3_plan(n_rows, cout, nkt, wm, ni, p, cus)) return 0;
+  if (out) {
+    if (out_len < 5 + (int64_t)p.G + 1) return 0;
+    out[0] = p.G; out[1] = (int32_t)p.q; out[2] = (int32_t)p.rem; out[3] = (int32_t)p.U; out[4] = p.dp_rounds;
+    for (int b = 0; b <= p.G; ++b) out[5 + b] = (int32_t)g3_bound((unsigned)b, p.q, p.rem, (unsigned)nkt, g3_snap != 0);
+  }
+  return p.G;
+}
 
 // Called by ofx_graphconv_fwd_planes (ofx_gemm2.hip) once it has filled the common arguments.
 // Returns OFX_OK (launched), a failure status, or 1 when the shape / workspace does not qualify (caller falls back

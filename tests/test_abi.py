@@ -126,3 +126,73 @@ def test_state_dict_boundary_at_the_real_configs():
         with torch.device('meta'):
             vae = GraphVAE(**kw)
         assert [[k, list(v.shape)] for k, v in vae.state_dict().items()] == rec['keys'], name
+
+
+def test_persistent_launch_schedule_invariants():
+    """The schedule of the persistent planes GraphConv (csrc/ofx_gemm3.hip: whole-tile rounds + a stream-K region) is
+    integer arithmetic shared by host and kernel (g3_bound): checked here on the CPU, through ofx_gconv3_plan, for the
+    layer shapes of the three configs at several batch sizes and for random shapes.
+      * the shares tile the region: bound(0) = 0, bound(G) = U, monotone;
+      * every piece -- share boundary to tile edge, or boundary to boundary inside one tile -- has >= 8 k-steps (the
+        kernel's loop shape), so no block ever gets an empty or too-short piece;
+      * rounds * G + region tiles = all tiles, and the region holds between G and 2G tiles when there are >= G tiles;
+      * shares of >= one tile (the 'early combine' regime) cut every tile at most once;
+      * nearest snapping keeps every share within 4 k-steps of the even split (the first version: 7)."""
+    import ctypes
+    import random
+    from octfusion_amd import _lib
+    L = _lib.lib()
+    KMIN = 8
+
+    def plan(n_rows, cout, nkt, wm, ni, cus=256):
+        buf = (ctypes.c_int32 * (5 + 2 * cus + 2))()
+        G = L.ofx_gconv3_plan(n_rows, cout, nkt, wm, ni, cus, buf, len(buf))
+        if G == 0:
+            return None
+        return dict(G=buf[0], q=buf[1], rem=buf[2], U=buf[3], rounds=buf[4], bounds=list(buf[5:5 + G + 1]))
+
+    rnd = random.Random(7)
+    shapes = []
+    for B in (1, 2, 4, 8):
+        for n1, d in ((27126, 6), (8450, 5), (4096, 4), (406050, 8), (96000, 7)):
+            for cin, cout in ((128, 128), (256, 128), (384, 128), (256, 256), (512, 256), (768, 256), (512, 512), (64, 64)):
+                shapes.append((n1 * B, cout, 7 * (cin // 32) + (7 * (d - 1) + 31) // 32))
+    for _ in range(300):
+        shapes.append((rnd.randint(1, 3_000_000), rnd.choice((64, 72, 128, 200, 256, 320, 512)), rnd.randint(1, 200)))
+    seen_early = seen_late = seen_rounds = 0
+    for n_rows, cout, nkt in shapes:
+        for wm, ni in ((4, 2), (2, 2), (4, 1), (2, 1)):
+            p = plan(n_rows, cout, nkt, wm, ni)
+            tiles = -(-n_rows // (wm * 64)) * -(-cout // (64 * ni))
+            if p is None:
+                assert nkt < KMIN or tiles * nkt < 2 * KMIN * 8 or tiles * nkt >= 2 ** 31, (n_rows, cout, nkt, wm, ni)
+                continue
+            G, U, b = p['G'], p['U'], p['bounds']
+            assert G % 8 == 0 and 8 <= G <= 256 * (1 if wm == 4 else 2)
+            region_tiles = tiles - p['rounds'] * G
+            assert U == region_tiles * nkt and p['q'] * G + p['rem'] == U
+            if tiles >= G and p['rounds'] >= 0 and tiles >= 256 * (1 if wm == 4 else 2):
+                assert G <= region_tiles < 2 * G, (tiles, G, p['rounds'])
+                seen_rounds += p['rounds'] > 0
+            assert b[0] == 0 and b[G] == U and all(b[i] <= b[i + 1] for i in range(G))
+            cuts = {}
+            for i in range(1, G):
+                t, r = divmod(b[i], nkt)
+                assert r == 0 or KMIN <= r <= nkt - KMIN, (n_rows, cout, nkt, wm, ni, i, b[i])
+                even = i * p['q'] + min(i, p['rem'])
+                assert abs(b[i] - even) <= (4 if nkt >= 2 * KMIN else KMIN), (b[i], even, nkt)
+                if r:
+                    cuts.setdefault(t, []).append(r)
+            for t, rs in cuts.items():            # pieces between two cuts inside one tile
+                rs = sorted(rs)
+                assert all(y - x >= KMIN for x, y in zip(rs, rs[1:])), (n_rows, cout, nkt, rs)
+            nonempty = [b[i + 1] - b[i] for i in range(G) if b[i + 1] > b[i]]
+            assert min(nonempty) >= KMIN
+            if p['rounds'] == 0:
+                assert len(nonempty) == G or tiles * nkt < G * 2 * KMIN + nkt, 'a block without work and without rounds'
+            if p['q'] >= nkt:
+                seen_early += 1
+                assert all(len(rs) == 1 for rs in cuts.values())
+            else:
+                seen_late += 1
+    assert seen_early > 50 and seen_late > 50 and seen_rounds > 20

@@ -971,12 +971,20 @@ __global__ void __launch_bounds__(256) splitk_reduce_v4_kernel(const GemmArgs g)
     const float* p = g.ws + m * g.N + n;
     float4 v = f4zero();
     int s = 0;
+    // (a thread's loads are a chain of memory round trips: eight in flight instead of four)
+    for (; s + 7 < g.nsplit; s += 8) {
+      float4 a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const float4*>(p + (int64_t)(s + u) * total);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) f4add(v, a[u]);                        // slice order, as the scalar kernel
+    }
     for (; s + 3 < g.nsplit; s += 4) {
       const float4 a0 = *reinterpret_cast<const float4*>(p + (int64_t)s * total);
       const float4 a1 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 1) * total);
       const float4 a2 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 2) * total);
       const float4 a3 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 3) * total);
-      f4add(v, a0); f4add(v, a1); f4add(v, a2); f4add(v, a3);            // slice order, as the scalar kernel
+      f4add(v, a0); f4add(v, a1); f4add(v, a2); f4add(v, a3);
     }
     for (; s < g.nsplit; ++s) f4add(v, *reinterpret_cast<const float4*>(p + (int64_t)s * total));
     if (g.bias) f4add(v, *reinterpret_cast<const float4*>(g.bias + n));
@@ -1111,6 +1119,8 @@ static int launch_gemm(GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st) 
   int nsplit = 1;
   const int tiles = g.ntm * g.ntn;
   if (ws && tiles < 256 && nkt >= 8) {
+    // (512 blocks aimed for, >= 4 k tiles per slice: swept in round 3 on the lr step -- 256 / 1024 blocks and 2 / 8
+    // k tiles are all 0 - 3 % slower)
     nsplit = (int)ofx_cdiv(512, tiles);
     if (nsplit > nkt / 4) nsplit = nkt / 4;
     if (nsplit > 64) nsplit = 64;

@@ -289,14 +289,19 @@ int ofx_graph_type_frac(const int32_t* seg_ptr, const int32_t* col, const uint8_
  * transposed nn.Linear [N,K] (sk = 1, sn = K) and -- when cin > 0 -- the
  * GraphConv row permutation: reference row dir*(cin+nt)+c (modules.py:174-176)
  * -> packed k = dir*cin + c for features, 7*cin + dir*nt + t for node types. */
-/* Contraction precision (process-wide): 0 = bf16x3 (default): activations and weights are
- * split into bf16 hi+lo pairs and a*w = a_hi*w_hi + a_lo*w_hi + a_hi*w_lo runs on the bf16
- * matrix pipe with fp32 accumulation -- ~1e-5 relative to an fp32 reference at 16/3 x the
- * fp32-MFMA rate; 1 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-equal to an fma chain);
- * 2 = reduced precision: the planes GraphConv runs ONE fp16 MFMA per product (operands rounded to fp16,
- * fp32 accumulate; ~5e-4 per product), every other contraction stays bf16x3.  Not thread-safe: set it
- * before launching work, from the thread that launches.
- * A packed-weight buffer holds the fp32 pack followed by the bf16 hi|lo planes:
+/* Contraction precision (process-wide).  Modes 0 and 3 split activations and weights into 16-bit hi + lo halves and
+ * run a*w = a_lo*w_hi + a_hi*w_lo + a_hi*w_hi on the 16-bit matrix pipe with fp32 accumulation, 16/3 x the fp32-MFMA
+ * rate:
+ *   3 = fp16x3 (DEFAULT since round 3): fp16 halves, 22 significand bits (operands beyond +-65504 saturate) --
+ *       whole-step element-wise error at the level of the reference's own fp32 arithmetic;
+ *   0 = bf16x3: bf16 halves, 16 significand bits, fp32's exponent range (~1e-5 per layer, 2e-3 element-wise through a
+ *       whole step);
+ *   1 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-equal to an fma chain);
+ *   2 = reduced precision: the planes GraphConv runs ONE fp16 MFMA per product (operands rounded to fp16, fp32
+ *       accumulate; ~5e-4 per product), every other contraction as mode 3's family.
+ * Not thread-safe: set it before launching work, from the thread that launches.  Packed weights and operand planes are
+ * mode-specific (re-pack after switching).
+ * A packed-weight buffer holds the fp32 pack followed by the 16-bit hi|lo planes of the mode it was packed in:
  * ofx_packed_floats(Kp, N) floats in total. */
 int ofx_set_precision(int mode);
 int ofx_get_precision(void);
@@ -344,14 +349,14 @@ int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes,
 /* ---------------------------------------------------------------- GraphConv on operand planes
  * Second implementation of the same operator (modules.py:194-220) for the layers that carry the step's
  * time: operands arrive PRE-SPLIT and are staged global -> LDS by DMA (csrc/ofx_gemm2.hip).
- *  "planes", mode 2 (bf16x3): every 32-channel chunk of a row is one 128-B line
- *      [bf16 hi x 32 | bf16 lo x 32], value = hi + lo (2^-17 relative): the bytes of the fp32 row, so a
+ *  "planes", mode 3 (fp16x3, the default precision) / mode 2 (bf16x3): every 32-channel chunk of a row is one
+ *      128-B line [hi x 32 | lo x 32] of fp16 / bf16 halves, value = hi + lo: the bytes of the fp32 row, so a
  *      planes tensor aliases an fp32-shaped [rows, C] buffer (row pitch = fp32 pitch, C % 32 == 0);
  *  mode 1 (single-pass fp16, reduced precision, ofx_set_precision(2)): fp16 row-major, C % 64 == 0.
- * ofx_planes_split: fp32 -> planes (columns C..Cpad-1 zero-filled; in place allowed for mode 2).
+ * ofx_planes_split: fp32 -> planes (columns C..Cpad-1 zero-filled; in place allowed for modes 2 and 3).
  * ofx_planes_merge: planes -> fp32 (tests).
  * ofx_gn_apply_planes: ofx_gn_apply (modules.py:311-314 + fused SiLU/GELU) writing planes; `out` may be x
- *      itself in mode 2.  With aux != NULL (then out must not alias x) the same launch also writes the consuming
+ *      itself in modes 2 and 3.  With aux != NULL (then out must not alias x) the same launch also writes the consuming
  *      GraphConv's aux rows (zero row + multi-neighbour means, from the CSR seg_ptr / col / multi_seg of that
  *      graph depth), and ofx_graphconv_fwd_planes is called with aux_ready = 1: one launch less per convolution.
  * ofx_pack_weights_planes: GraphConv weights [7*(cin+nt'), cout] (element (k, n) at W[k*sk + n*sn]) ->

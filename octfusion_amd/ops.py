@@ -53,8 +53,8 @@ def set_precision(mode):
     """'fp16x3' (default): operands as fp16 hi + lo pairs, three fp16 MFMAs per product, fp32 accumulate -- the fp32
     reference's rounding class (~2^-21 per product) on the 16-bit matrix pipe;
     'bf16x3': the same scheme with bf16 pairs (2^-16 per product; rounds 1-2's default, kept for A/B);
-    'fp32' (exact fp32 MFMA); 'fp16' (reduced precision: single-pass fp16 MFMA in the planes GraphConv, everything
-    else bf16x3)."""
+    'fp32' (exact fp32 MFMA); 'fp16' (reduced precision: single-pass fp16 MFMA in the planes GraphConv, every other
+    contraction in 16-bit pairs)."""
     call('ofx_set_precision', PRECISIONS[mode])
 
 
@@ -74,7 +74,8 @@ POLICY = {'dense_net': None, 'small_gemm': None}
 
 @contextlib.contextmanager
 def policy_scope(part):
-    """Run the enclosed launches in POLICY[part] when the global mode is the default one."""
+    """Run the enclosed launches in POLICY[part] when the global mode is 'bf16x3' (no-op in every other mode and while
+    POLICY[part] is None, the shipped setting)."""
     want = POLICY.get(part)
     L = _lib.lib()
     if want is None or L.ofx_get_precision() != PRECISIONS['bf16x3'] or want == 'bf16x3':
@@ -98,7 +99,8 @@ PLANES_MIN_TILES = int(os.environ.get('OFX_PLANES_MIN_TILES', '32'))
 
 
 def planes_mode():
-    """0: off, 2: bf16x3 planes, 1: fp16 planes -- follows the contraction precision."""
+    """Planes format that goes with the contraction precision: 3 = fp16 pairs (fp16x3), 2 = bf16 pairs (bf16x3),
+    1 = single fp16 (reduced precision), 0 = none (exact fp32, or USE_PLANES off)."""
     if not USE_PLANES:
         return 0
     code = _lib.lib().ofx_get_precision()

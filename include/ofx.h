@@ -298,7 +298,7 @@ int ofx_graph_type_frac(const int32_t* seg_ptr, const int32_t* col, const uint8_
  *       whole step);
  *   1 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-equal to an fma chain);
  *   2 = reduced precision: the planes GraphConv runs ONE fp16 MFMA per product (operands rounded to fp16, fp32
- *       accumulate; ~5e-4 per product), every other contraction as mode 3's family.
+ *       accumulate; ~5e-4 per product), every other contraction in bf16 pairs.
  * Not thread-safe: set it before launching work, from the thread that launches.  Packed weights and operand planes are
  * mode-specific (re-pack after switching).
  * A packed-weight buffer holds the fp32 pack followed by the 16-bit hi|lo planes of the mode it was packed in:

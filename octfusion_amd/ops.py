@@ -54,7 +54,7 @@ def set_precision(mode):
     reference's rounding class (~2^-21 per product) on the 16-bit matrix pipe;
     'bf16x3': the same scheme with bf16 pairs (2^-16 per product; rounds 1-2's default, kept for A/B);
     'fp32' (exact fp32 MFMA); 'fp16' (reduced precision: single-pass fp16 MFMA in the planes GraphConv, every other
-    contraction in 16-bit pairs)."""
+    contraction in bf16 pairs)."""
     call('ofx_set_precision', PRECISIONS[mode])
 
 

@@ -234,6 +234,43 @@ def test_unet(golden):
     torch.testing.assert_close(y, r['out'], rtol=2e-4, atol=2e-5)
 
 
+def test_float64_oracle_is_the_same_algorithm(golden):
+    """The precision contract (tests/test_gpu_precision.py, profiles/r03/precision_attribution.json) measures the product
+    against the oracle run in float64 (oracle.modules.working_float).  That yardstick is pinned here, on the CPU: on
+    the golden nets the float64 run must sit as close to the REFERENCE's recorded output as the float32 run does (same
+    op sequence -- the difference between the two is rounding noise, far below the test tolerance of the goldens), and
+    its result must really be float64 all the way (a silent down-cast anywhere would leave fp32-sized noise between two
+    float64 runs at different thread counts / summation blockings; here: exact equality of two runs, and a distance to
+    the float32 run that is of fp32 size, not zero)."""
+    from oracle import modules as OM
+    G = golden('g_unet')
+    oc, doc = small(G['split_small'])
+
+    def dbl(x):
+        if isinstance(x, dict):
+            return {k: dbl(v) for k, v in x.items()}
+        return x.double() if torch.is_tensor(x) and x.is_floating_point() else x
+
+    for name in ['uncond', 'cond']:
+        r = G[name]
+        parts = split_union_sd(C.fill_state_dict(r['keys']))
+        hr = dict(C.TINY_HR_CFG, num_classes=r['num_classes'])
+        lr = dict(C.TINY_LR_CFG, num_classes=r['num_classes'])
+        y32 = OU.hr_forward(parts['unet_hr'], hr, r['x'], doc, r['t'], r['label'], parts['unet_lr'], lr)
+        with OM.working_float(torch.float64):
+            p64 = dbl(parts)
+            y64 = OU.hr_forward(p64['unet_hr'], hr, r['x'].double(), doc, r['t'].double(), r['label'], p64['unet_lr'], lr)
+            y64b = OU.hr_forward(p64['unet_hr'], hr, r['x'].double(), doc, r['t'].double(), r['label'], p64['unet_lr'], lr)
+        assert OM.FLOAT == torch.float32                       # the context manager restores the reference arithmetic
+        assert y64.dtype == torch.float64 and torch.equal(y64, y64b)
+        scale = float(r['out'].abs().max())
+        d_ref = float((y64.float() - r['out']).abs().max()) / scale
+        d_32 = float((y32 - r['out']).abs().max()) / scale
+        d_6432 = float((y64 - y32.double()).abs().max()) / scale
+        assert d_ref < 2e-5 and d_32 < 2e-5, (name, d_ref, d_32)
+        assert 1e-9 < d_6432 < 2e-5, (name, d_6432)            # fp32-sized, and not zero: the two runs do differ in arithmetic
+
+
 def fake_net(shape):
     A = torch.linspace(-0.5, 0.5, shape[1])
 

@@ -16,9 +16,12 @@ import os
 import torch
 
 
-def _read(ckpt):
+def _read(ckpt, allow_pickle=False):
+    """A checkpoint file -> its dict.  The formats above hold tensors, numbers and plain containers only, so the file is
+    read with torch's restricted unpickler; allow_pickle=True (a file you trust that carries other Python objects, e.g.
+    an option namespace) falls back to the full one."""
     if isinstance(ckpt, (str, os.PathLike)):
-        return torch.load(ckpt, map_location='cpu', weights_only=False)
+        return torch.load(ckpt, map_location='cpu', weights_only=not allow_pickle)
     return ckpt
 
 
@@ -26,13 +29,13 @@ STAGE_NETS = ('unet_lr', 'unet_hr', 'unet_feature')
 _STAGES_UP_TO = {'lr': 1, 'hr': 2, 'feature': 3}
 
 
-def load_ckpt(ckpt, df, ema_df=None, load_options=STAGE_NETS, opt=None):
+def load_ckpt(ckpt, df, ema_df=None, load_options=STAGE_NETS, opt=None, allow_pickle=False):
     """octfusion_model_union.py:525-545 / octfusion_model_union_3t.py:250-261.  df / ema_df: union UNet3DModel
     instances (ema_df may be None or df itself at inference); every stage net present in BOTH the file and `df` and
     named in load_options is loaded strictly.  opt: optional training.AdamW whose state is restored from 'opt' when
     the file holds one written by save_ckpt (a torch.optim state from the reference is keyed by parameter index and
     is not convertible without the reference's parameter order: ignored).  Returns the checkpoint's global_step."""
-    sd = _read(ckpt)
+    sd = _read(ckpt, allow_pickle)
     for name in STAGE_NETS:
         if name in load_options and 'df_' + name in sd and getattr(df, name, None) is not None:
             getattr(df, name).load_state_dict(sd['df_' + name], strict=True)
@@ -53,9 +56,9 @@ def save_ckpt(path, df, ema_df, global_step, stage_flag='hr', opt_state=None):
     torch.save(sd, path)
 
 
-def vae_state_dict(ckpt):
+def vae_state_dict(ckpt, allow_pickle=False):
     """models/model_utils.py:18-28: unwrap the three layouts a GraphVAE checkpoint comes in."""
-    sd = _read(ckpt)
+    sd = _read(ckpt, allow_pickle)
     if isinstance(ckpt, (str, os.PathLike)) and str(ckpt).endswith('.solver.tar'):
         sd = sd['model_dict']
     if 'autoencoder' in sd:
@@ -63,19 +66,19 @@ def vae_state_dict(ckpt):
     return sd
 
 
-def load_vae(ckpt, vae):
-    vae.load_state_dict(vae_state_dict(ckpt), strict=True)
+def load_vae(ckpt, vae, allow_pickle=False):
+    vae.load_state_dict(vae_state_dict(ckpt, allow_pickle), strict=True)
     return vae.eval()
 
 
 def read_splits(sample_dir, device):
     """A sample directory of the reference's dataset (dualoctree_snet.py:137-151) -> (split_small [1,8,S,S,S],
     split_large [nnum6, 8] or None) on `device`."""
-    small = torch.load(os.path.join(sample_dir, 'split_small.pth'), map_location='cpu', weights_only=False)
+    small = torch.load(os.path.join(sample_dir, 'split_small.pth'), map_location='cpu', weights_only=True)
     if small.dim() == 4:
         small = small.unsqueeze(0)                  # gen_split.py:52 squeezes the batch dim
     p = os.path.join(sample_dir, 'split_large.pth')
-    large = torch.load(p, map_location='cpu', weights_only=False) if os.path.exists(p) else None
+    large = torch.load(p, map_location='cpu', weights_only=True) if os.path.exists(p) else None
     return small.to(device), (large.to(device) if large is not None else None)
 
 

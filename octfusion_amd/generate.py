@@ -29,7 +29,7 @@ from .graph_unet_union import UNet3DModel
 from .pipeline import CascadeSampler
 
 
-def build_models(config, ckpt=None, vae_ckpt=None, with_vae=True, rank=0):
+def build_models(config, ckpt=None, vae_ckpt=None, with_vae=True, rank=0, allow_pickle=False):
     """(net with EMA weights, vae or None) on the CPU; only rank 0 reads files / draws the synthetic weights."""
     cfg = configs.CONFIGS[config]
     stage = cfg['unet_type'][-1]
@@ -42,12 +42,12 @@ def build_models(config, ckpt=None, vae_ckpt=None, with_vae=True, rank=0):
         if ckpt:
             # `net` plays both roles of load_ckpt: the df_* weights are loaded first and then overwritten by ema_df_*,
             # so a file whose two sets differ leaves the EMA set in the sampling net
-            checkpoint.load_ckpt(ckpt, net, ema_df=net)
+            checkpoint.load_ckpt(ckpt, net, ema_df=net, allow_pickle=allow_pickle)
         else:
             net.load_state_dict(synthetic.random_state_dict(net))
         if vae is not None:
             if vae_ckpt:
-                checkpoint.load_vae(vae_ckpt, vae)
+                checkpoint.load_vae(vae_ckpt, vae, allow_pickle=allow_pickle)
             else:
                 vae.load_state_dict(synthetic.random_state_dict(vae))
     return net, vae
@@ -60,10 +60,10 @@ def plan(n_shapes, rank, world, shapes_per_call):
     return [mine[g0:g0 + shapes_per_call] for g0 in range(0, len(mine), shapes_per_call)]
 
 
-def prepare(config, rank, device, ckpt=None, vae_ckpt=None, with_vae=True):
+def prepare(config, rank, device, ckpt=None, vae_ckpt=None, with_vae=True, allow_pickle=False):
     """(net, vae, bytes broadcast): models on `device` with rank 0's weights on every rank -- ONE flat broadcast per
     model, U-Net and VAE."""
-    net, vae = build_models(config, ckpt, vae_ckpt, with_vae=with_vae, rank=rank)
+    net, vae = build_models(config, ckpt, vae_ckpt, with_vae=with_vae, rank=rank, allow_pickle=allow_pickle)
     net = net.to(device).eval()
     nbytes = dist.broadcast_module_(net, src=0)
     if vae is not None:
@@ -110,7 +110,8 @@ def write_outputs(out_dir, idxs, out, cfg):
 
 def run(args, rank, local_rank, world, device):
     cfg = configs.CONFIGS[args.config]
-    net, vae, nbytes = prepare(args.config, rank, device, args.ckpt, args.vae, with_vae=not args.no_vae)
+    net, vae, nbytes = prepare(args.config, rank, device, args.ckpt, args.vae, with_vae=not args.no_vae,
+                               allow_pickle=getattr(args, 'allow_pickle', False))
     label = args.category if cfg.get('num_classes') else None
     if cfg.get('num_classes') and label is None:
         label = 0
@@ -142,6 +143,8 @@ def main(argv=None):
     ap.add_argument('--ckpt', default=None, help='df_*.pth (the EMA weights are used, as the reference does)')
     ap.add_argument('--vae', default=None, help='GraphVAE checkpoint (seeded random weights when absent)')
     ap.add_argument('--no-vae', action='store_true', help='stop after the last DDIM stage (no decode, no SDF)')
+    ap.add_argument('--allow-pickle', action='store_true',
+                    help='read the checkpoint files with the full unpickler (only for files you trust)')
     ap.add_argument('--sdf-resolution', type=int, default=256)
     ap.add_argument('--out', default=None)
     args = ap.parse_args(argv)

@@ -207,3 +207,52 @@ def test_generate_samples_with_ema_weights(tmp_path):
     assert list(want) == list(have)
     assert all(torch.equal(want[k], have[k]) for k in want)
     assert not all(torch.equal(other[k], have[k]) for k in want)
+
+
+def test_checkpoint_files_are_read_with_the_restricted_unpickler(tmp_path):
+    """Checkpoints and sample files are data from elsewhere: the reference's formats hold tensors, numbers and plain
+    containers (octfusion_model_union.py:501-523, model_utils.py:18-28, gen_split.py:50-54), so they load under
+    torch's weights-only unpickler -- including the optimiser dict a reference-trained file carries; a file that smuggles
+    another Python object is refused unless the caller says it trusts it (allow_pickle=True)."""
+    import pickle
+    import pytest
+    sys.path.insert(0, ROOT)
+    from octfusion_amd import checkpoint
+    lin = torch.nn.Linear(4, 3)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.unet_lr = torch.nn.Linear(4, 3)
+    df, ema = Net(), Net()
+    adam = torch.optim.Adam(df.parameters())
+    df.unet_lr(torch.ones(2, 4)).sum().backward()
+    adam.step()
+    good = {'df_unet_lr': df.unet_lr.state_dict(), 'ema_df_unet_lr': ema.unet_lr.state_dict(), 'opt': adam.state_dict(),
+            'global_step': 7}
+    p_good = str(tmp_path / 'df_good.pth')
+    torch.save(good, p_good)
+    fresh = Net()
+    assert checkpoint.load_ckpt(p_good, fresh, fresh) == 7
+    assert torch.equal(fresh.unet_lr.weight, ema.unet_lr.weight)
+
+    class Payload:
+        def __reduce__(self):
+            return (print, ('executed while unpickling',))
+    p_bad = str(tmp_path / 'df_bad.pth')
+    torch.save(dict(good, extra=Payload()), p_bad)
+    with pytest.raises(pickle.UnpicklingError):
+        checkpoint.load_ckpt(p_bad, Net(), None)
+    assert checkpoint.load_ckpt(p_bad, Net(), None, allow_pickle=True) == 7
+    # VAE layouts and sample files
+    for name, obj in (('vae.pth', lin.state_dict()), ('vae_wrapped.pth', {'autoencoder': lin.state_dict()}),
+                      ('vae.solver.tar', {'model_dict': lin.state_dict(), 'epoch': 3})):
+        path = str(tmp_path / name)
+        torch.save(obj, path)
+        sd = checkpoint.vae_state_dict(path)
+        assert torch.equal(sd['weight'], lin.weight)
+    d = tmp_path / 'sample'
+    d.mkdir()
+    torch.save(torch.ones(8, 16, 16, 16), str(d / 'split_small.pth'))
+    small, large = checkpoint.read_splits(str(d), 'cpu')
+    assert small.shape == (1, 8, 16, 16, 16) and large is None

@@ -20,6 +20,35 @@ from .dual_octree import DualOctree
 from .octree import split2octree_large, split2octree_small
 
 
+class StepNoise:
+    """``step_noise`` of sampler.sample_loop for a stage whose per-step tensors are too large to draw up front (the
+    feature stage at B = 8: 200 steps x 39 MB): element i is drawn when the loop asks for it.  It is a STREAM -- the
+    reference draws on every x0-branch step, used or not (octfusion_model_union.py:338-343) -- so steps that are never
+    asked for are still drawn, in order, and an element can be asked for once, in step order."""
+
+    def __init__(self, draw, n):
+        self._draw, self._n, self._pos = draw, n, 0
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if not self._pos <= i < self._n:
+            raise IndexError('step noise is a stream: element %d asked for after %d were drawn' % (i, self._pos))
+        while self._pos < i:
+            self._draw()                     # a step that used no noise: its draw is consumed all the same
+            self._pos += 1
+        self._pos += 1
+        return self._draw()
+
+    def finish(self):
+        """Consume the draws nobody asked for (the last step of a stage uses no noise, the reference draws it anyway):
+        the next stage of a model that does not reseed continues the same streams."""
+        while self._pos < self._n:
+            self._draw()
+            self._pos += 1
+
+
 class CascadeSampler:
     def __init__(self, net, cfg, vae=None, device=None):
         """net: graph_unet_union.UNet3DModel (EMA weights); cfg: a dict from octfusion_amd.configs."""
@@ -74,10 +103,7 @@ class CascadeSampler:
                                     for g, n in zip(gens, counts)])
             return out
         init = draw()
-        steps = [None] * ddim_steps
-        if df_type == 'x0':
-            for i in range(ddim_steps):
-                steps[i] = draw()
+        steps = StepNoise(draw, ddim_steps) if df_type == 'x0' else [None] * ddim_steps
         return init, steps
 
     @torch.no_grad()
@@ -143,6 +169,8 @@ class CascadeSampler:
         x = sampler.sample_loop(self.net, (doctree.total_num, self.cfg['input_channels'][1]), batch_size, ddim_steps,
                                 'hr', self.df_type[1], self.device, doctree=doctree, unet_lr=self.net.unet_lr,
                                 label=label, init_noise=n.get('init'), step_noise=n.get('steps'), use_graph=use_graph)
+        if isinstance(n.get('steps'), StepNoise):
+            n['steps'].finish()
         out['hr'] = x
         t0 = lap('hr_steps', t0)
         if len(self.stages) >= 3:
@@ -161,6 +189,8 @@ class CascadeSampler:
                                     ddim_steps, 'feature', self.df_type[2], self.device, doctree=doctree,
                                     unet_lr=self.net.unet_hr, label=label, init_noise=n.get('init'),
                                     step_noise=n.get('steps'), use_graph=use_graph)
+            if isinstance(n.get('steps'), StepNoise):
+                n['steps'].finish()
             out['feature'] = x
             t0 = lap('feature_steps', t0)
         out['doctree'] = doctree

@@ -256,3 +256,33 @@ def test_checkpoint_files_are_read_with_the_restricted_unpickler(tmp_path):
     torch.save(torch.ones(8, 16, 16, 16), str(d / 'split_small.pth'))
     small, large = checkpoint.read_splits(str(d), 'cpu')
     assert small.shape == (1, 8, 16, 16, 16) and large is None
+
+
+def test_step_noise_stream_semantics():
+    """pipeline.StepNoise: the lazily drawn per-step noise of a sparse x0 stage is the same sequence an up-front draw
+    gives -- including the draws of steps that never ask for noise -- and refuses out-of-order or repeated access
+    instead of silently handing out a different sample."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    from octfusion_amd.pipeline import StepNoise
+    g = torch.Generator().manual_seed(5)
+    eager = [torch.randn(7, 3, generator=g) for _ in range(9)]
+    g2 = torch.Generator().manual_seed(5)
+    lazy = StepNoise(lambda: torch.randn(7, 3, generator=g2), 9)
+    assert len(lazy) == 9
+    for i in (0, 1, 4, 5, 8):                      # steps 2, 3, 6, 7 use no noise: their draws are consumed anyway
+        assert torch.equal(lazy[i], eager[i])
+    with pytest.raises(IndexError):
+        lazy[8]                                    # asked for twice
+    # finish(): the draws nobody asked for are consumed, so that the stream continues where an up-front draw leaves it
+    g3 = torch.Generator().manual_seed(5)
+    lazy3 = StepNoise(lambda: torch.randn(7, 3, generator=g3), 9)
+    lazy3[2]
+    lazy3.finish()
+    assert torch.equal(torch.randn(7, 3, generator=g3), torch.randn(7, 3, generator=g))   # both streams: 9 draws behind them
+    lazy2 = StepNoise(lambda: torch.zeros(1), 3)
+    lazy2[1]
+    with pytest.raises(IndexError):
+        lazy2[0]                                   # out of order
+    with pytest.raises(IndexError):
+        lazy2[3]

@@ -254,3 +254,35 @@ def test_stage_step_freezes_the_nested_net(golden):
     for k, v in net.unet_lr.state_dict().items():
         assert torch.equal(v, before[k]), 'nested lr parameter %s changed' % k
     assert any(not torch.equal(v, hr_before[k]) for k, v in net.unet_hr.state_dict().items())
+
+
+def test_batched_three_stage_sampling_with_lazy_step_noise():
+    """CascadeSampler.sample(shape_indices=) on the 3-stage model: the sparse x0 stages draw their per-step noise
+    lazily (pipeline.StepNoise; the feature stage's 200 tensors would be gigabytes up front).  Same samples as with
+    every tensor drawn up front, and a batch of two equals the two shapes sampled alone."""
+    from octfusion_amd import pipeline, synthetic
+    from octfusion_amd.graph_unet_union import UNet3DModel
+    net = UNet3DModel(**{k: v for k, v in dict(CFG3, stage_flag='feature').items() if k != 'df_type'})
+    net.load_state_dict(synthetic.random_state_dict(net))
+    net = net.to(dev()).eval()
+    cs = pipeline.CascadeSampler(net, CFG3, None)
+    steps, seed, idxs = 5, 21, [6, 2]
+    lazy = cs.sample(2, ddim_steps=steps, seed=seed, shape_indices=idxs, use_graph=False)
+
+    class Eager(list):
+        def __init__(self, draw, n):
+            super().__init__(draw() for _ in range(n))
+
+        def finish(self):
+            pass
+    saved = pipeline.StepNoise
+    pipeline.StepNoise = Eager
+    try:
+        eager = cs.sample(2, ddim_steps=steps, seed=seed, shape_indices=idxs, use_graph=False)
+    finally:
+        pipeline.StepNoise = saved
+    for k in ('split_small', 'hr', 'feature'):
+        assert torch.equal(lazy[k], eager[k]), k
+    replay = cs.sample(2, ddim_steps=steps, seed=seed, shape_indices=idxs)          # hipGraph replay path
+    assert torch.equal(replay['split_small'], lazy['split_small'])
+    assert replay['feature'].shape == lazy['feature'].shape

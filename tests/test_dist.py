@@ -226,7 +226,8 @@ def test_checkpoint_files_are_read_with_the_restricted_unpickler(tmp_path):
             self.unet_lr = torch.nn.Linear(4, 3)
     df, ema = Net(), Net()
     adam = torch.optim.Adam(df.parameters())
-    df.unet_lr(torch.ones(2, 4)).sum().backward()
+    with torch.enable_grad():                       # (GPU test modules switch autograd off process-wide at import)
+        df.unet_lr(torch.ones(2, 4)).sum().backward()
     adam.step()
     good = {'df_unet_lr': df.unet_lr.state_dict(), 'ema_df_unet_lr': ema.unet_lr.state_dict(), 'opt': adam.state_dict(),
             'global_step': 7}

@@ -144,6 +144,22 @@ def timed(fn, n_sync=True):
     return time.perf_counter() - t0
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max / v1 cfs quota), or None if unlimited.
+    The GPU boxes of this project show 256 logical CPUs and a quota of 16: every CPU figure has to live inside it."""
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        return None if q == 'max' else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -154,19 +170,12 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(name, batch):
-    """The reference's CPU path restated (oracle/), timed on this host's cores on a bounded sample of the same
-    workload (fp32, warm-ups then >= 5 timed steps; B = 1 shape per step for the sparse
-    stages, scaled to the per-GPU batch by division)."""
+def _cpu_stepper(name, batch):
+    """(step(i, x) -> x, x0, shapes per step) of the reference's CPU path restated (oracle/) for workload `name`."""
     from octfusion_amd import configs, synthetic
     from octfusion_amd.graph_unet_union import UNet3DModel
     from oracle import dual_octree as OD, modules as OM, sampler as OS, unet as OU
     w = WORKLOADS[name]
-    # torch-CPU scatter / index ops collapse when oversubscribed (256 threads: 140 s per hr step measured on the GPU
-    # box in round 1, vs 1.3 s with 32), so the thread count is capped at 32 -- both numbers are reported.
-    ncpu = os.cpu_count() or 1
-    threads = min(32, ncpu)
-    torch.set_num_threads(threads)
     net = UNet3DModel(**configs.unet_params(w['config'], w['stage']))
     sd = synthetic.random_state_dict(net)
     st = configs.stage_cfgs(w['config'])
@@ -206,25 +215,111 @@ def cpu_baseline(name, batch):
             x0 = (x - out * s[0]) / a[0].clamp(min=1e-8)
             return x0 * an[0] + out * sn[0]
         return out * an[0] + (x - a[0] * out) / s[0].clamp(min=1e-8) * sn[0]          # deterministic x0-branch update
+    return step, x, bs
 
-    n_warm, n_timed = w['cpu']
+
+def _cpu_time_steps(name, batch, n_warm, n_timed, threads, sync_dir=None, k=0, n_workers=1):
+    """n_warm + n_timed oracle steps with `threads` torch threads; with sync_dir the timed part starts when all
+    n_workers workers have finished their warm-up (file rendezvous)."""
+    torch.set_num_threads(threads)
+    step, x, bs = _cpu_stepper(name, batch)
     with torch.no_grad():
         t0 = time.perf_counter()
         for i in range(n_warm):
             x = step(i, x)
         tw = time.perf_counter() - t0
+        if sync_dir:
+            open(os.path.join(sync_dir, 'ready_%d' % k), 'w').close()
+            t_wait = time.time()
+            while len([f for f in os.listdir(sync_dir) if f.startswith('ready_')]) < n_workers and time.time() - t_wait < 300:
+                time.sleep(0.01)
+        w0 = time.time()
         t0 = time.perf_counter()
         for i in range(n_timed):
             x = step(n_warm + i, x)
         dt = time.perf_counter() - t0
-    shape_steps = bs * n_timed / dt
-    return {'value': shape_steps / batch, 'unit': 'denoising-steps/sec (batch %d)' % batch, 'cores': threads,
-            'kind': 'port', 'host_cpu_count': ncpu, 'cpu_model': cpu_model(), 'threads_used': threads,
-            'sample': 'oracle (torch-CPU restatement of the reference op sequence), %s, %d shape(s) per step, '
-                      '%d warm-up + %d timed steps in %.1f s (+%.1f s warm-up); shape-steps/s / %d'
-                      % (w['config'] + ' ' + stage, bs, n_warm, n_timed, dt, tw, batch),
-            'threads_note': 'torch CPU scatter/index collapses when oversubscribed (all %d logical CPUs: 140 s per '
-                            'hr step in round 1); 32 threads is the fastest setting found' % ncpu}
+    return {'dt': dt, 'warm': tw, 'shapes_per_step': bs, 'wall_start': w0, 'wall_end': w0 + dt}
+
+
+def cpu_worker_main(argv):
+    """`bench.py --cpu-worker name batch k n_workers cpus_per_worker n_warm n_timed sync_dir`: one pinned worker of the
+    whole-box CPU baseline."""
+    name, batch, k, n_workers, per, n_warm, n_timed = argv[0], int(argv[1]), int(argv[2]), int(argv[3]), int(argv[4]), int(argv[5]), int(argv[6])
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, set(allowed[k * per:(k + 1) * per]))
+    except (AttributeError, OSError):
+        pass
+    print(json.dumps(_cpu_time_steps(name, batch, n_warm, n_timed, per, argv[7], k, n_workers)))
+
+
+def cpu_baseline(name, batch):
+    """The reference's CPU path restated (oracle/), timed on this host's cores on a bounded sample of the same
+    workload (fp32, warm-ups then timed steps; B = 1 shape per step for the sparse stages,
+    scaled to the per-GPU batch by division).  Two figures:
+      * one process, 32 torch threads (torch-CPU scatter / index ops collapse when one process is given all threads:
+        140 s per hr step with 256 threads in round 1, 1.3 s with 32);
+      * the WHOLE BOX when it has more than 64 USABLE CPUs (affinity and cgroup quota): usable // 32 processes, each
+        pinned to its own 32 logical CPUs, one shape each, running concurrently -- `value` is the better of the two."""
+    import tempfile
+    w = WORKLOADS[name]
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu_allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        ncpu_allowed = ncpu
+    quota = cgroup_cpu_quota()
+    usable = ncpu_allowed if quota is None else max(1, min(ncpu_allowed, int(quota + 0.5)))
+    threads = min(32, usable)
+    n_warm, n_timed = w['cpu']
+    r1 = _cpu_time_steps(name, batch, n_warm, n_timed, threads)
+    single = r1['shapes_per_step'] * n_timed / r1['dt'] / batch
+    res = {'value': single, 'unit': 'denoising-steps/sec (batch %d)' % batch, 'cores': threads,
+           'kind': 'port', 'host_cpu_count': ncpu, 'cgroup_cpu_quota': quota, 'usable_cpus': usable,
+           'cpu_model': cpu_model(), 'threads_used': threads,
+           'single_process': {'value': single, 'threads': threads, 'timed_s': r1['dt'], 'warmup_s': r1['warm']},
+           'sample': 'oracle (torch-CPU restatement of the reference op sequence), %s, %d shape(s) per step, '
+                     '%d warm-up + %d timed steps in %.1f s (+%.1f s warm-up); shape-steps/s / %d'
+                     % (w['config'] + ' ' + w['stage'], r1['shapes_per_step'], n_warm, n_timed, r1['dt'], r1['warm'], batch),
+           'threads_note': 'threads = min(32, usable CPUs); usable = min(affinity, cgroup CPU quota).  The GPU boxes show '
+                           '%d logical CPUs under a quota of %s CPUs: more runnable threads than the quota are throttled '
+                           '(256 threads: 140 s per hr step, round 1; 8 pinned 32-thread processes: 32 s per step each, '
+                           'round 4), so the whole USABLE box is what one process with that many threads gets'
+                           % (ncpu, 'no' if quota is None else '%g' % quota)}
+    per = int(os.environ.get('OFX_CPU_WORKER_THREADS', '32'))      # (override: tests on small hosts)
+    n_workers = min(8, usable // per)
+    if n_workers >= 2:
+        nw_warm, nw_timed = max(1, n_warm - 1), max(2, n_timed - 1)
+        with tempfile.TemporaryDirectory() as sd:
+            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', name, str(batch), str(k),
+                                       str(n_workers), str(per), str(nw_warm), str(nw_timed), sd],
+                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                      env=dict(os.environ, OMP_NUM_THREADS=str(per), MKL_NUM_THREADS=str(per)))
+                     for k in range(n_workers)]
+            outs = []
+            deadline = time.time() + 150.0             # bounded: the default bench run has to finish within minutes
+            for p_ in procs:
+                try:
+                    o, _ = p_.communicate(timeout=max(1.0, deadline - time.time()))
+                    outs.append(json.loads([l for l in o.splitlines() if l.startswith('{')][-1]))
+                except Exception:      # noqa: BLE001
+                    p_.kill()
+        if len(outs) == n_workers:
+            # every worker runs its timed steps while all the others do (common start after the warm-ups): the box's
+            # rate is the sum of the workers' rates
+            rate = sum(o['shapes_per_step'] * nw_timed / o['dt'] for o in outs) / batch
+            overlap = min(o['wall_end'] for o in outs) - max(o['wall_start'] for o in outs)
+            res['whole_box'] = {'value': rate, 'processes': n_workers, 'threads_per_process': per,
+                                'cores': per * n_workers, 'pinned': 'disjoint blocks of %d logical CPUs (sched_setaffinity)' % per,
+                                'timed_s_per_worker': [o['dt'] for o in outs], 'steps_per_worker': nw_timed,
+                                'common_window_s': overlap,
+                                'sample': '%d concurrent workers, one shape each, %d warm-up + %d timed steps' % (n_workers, nw_warm, nw_timed)}
+            if rate > res['value']:
+                res['value'], res['cores'] = rate, per * n_workers
+                res['sample'] += '; value = whole box: %d pinned %d-thread processes, one shape each' % (n_workers, per)
+        else:
+            res['whole_box'] = {'error': '%d of %d workers returned' % (len(outs), n_workers)}
+    return res
 
 
 def parity_spot_check(wl, dev):
@@ -277,7 +372,7 @@ def gather_microbench(doc, dev, C=128, iters=20):
 
 
 KERNEL_SOURCES = ('ofx_gemm3.hip', 'ofx_planes.h', 'ofx_gemm2.hip', 'ofx_gemm.hip', 'ofx_gemm_common.h')
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r03', 'pmc_traffic.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r04', 'pmc_traffic.json')
 
 
 def kernel_source_hash():
@@ -304,6 +399,52 @@ def profile_summary(prof, dt_s, kinds, peak_tf):
             'time_frac_of_step': t_s / dt_s}
 
 
+TAIL_BOUND = {'dense_gemm': 'mfma', 'gridconv_27tap': 'mfma', 'attention': 'mfma'}       # every other class: HBM
+
+
+def tail_summary(tail, steps, peak_tf, step_ms):
+    """roofline_tail: everything of a step that is NOT the fused GraphConv, per kernel class.  `tail` = the
+    (entry point, start event, end event, meta) records of _lib.PROFILE over `steps` eager steps; a class's time is
+    the sum of its entry-point brackets (a bracket includes the launch's own second-stage kernels: split-K reduce,
+    statistics reduce); flops / bytes are the ALGORITHMIC ones of the operator (ops._meta)."""
+    cls = {}
+    shapes = {}
+    conv_ms = 0.0
+    for name, e0, e1, meta in tail:
+        ms = e0.elapsed_time(e1)
+        if name in ('ofx_graphconv_fwd_planes', 'ofx_graphconv_fwd'):
+            conv_ms += ms
+            continue
+        kind, fl, nb, tag = meta if meta is not None else (name.replace('ofx_', ''), 0.0, 0.0, None)
+        c = cls.setdefault(kind, [0, 0.0, 0.0, 0.0])
+        c[0] += 1; c[1] += ms; c[2] += fl; c[3] += nb
+        if tag is not None:
+            sh = shapes.setdefault((kind,) + tuple(tag), [0, 0.0, fl, nb])
+            sh[0] += 1; sh[1] += ms
+    rows = {}
+    tot_ms = tot_n = 0.0
+    for kind, (n, ms, fl, nb) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
+        bound = TAIL_BOUND.get(kind, 'hbm')
+        t_s = ms * 1e-3
+        r = {'launches_per_step': n / steps, 'ms_per_step': ms / steps, 'bound': bound,
+             'algorithmic_GFLOP_per_step': fl / steps / 1e9, 'algorithmic_MB_per_step': nb / steps / 1e6,
+             'TFLOPs': fl / t_s / 1e12 if t_s else None, 'GBps': nb / t_s / 1e9 if t_s else None}
+        r['frac'] = (r['TFLOPs'] / peak_tf if bound == 'mfma' else r['GBps'] / HBM_PEAK_GBS) if t_s else None
+        rows[kind] = r
+        tot_ms += ms; tot_n += n
+    top = sorted(shapes.items(), key=lambda kv: -kv[1][1])[:16]
+    return {'classes': rows, 'entry_point_calls_per_step': tot_n / steps, 'ms_per_step': tot_ms / steps,
+            'graphconv_entry_ms_per_step': conv_ms / steps,
+            'unattributed_ms_per_step': step_ms - (tot_ms + conv_ms) / steps,
+            'peaks': {'mfma_TFLOPs_for_algorithmic_flops': peak_tf, 'hbm_GBps': HBM_PEAK_GBS},
+            'top_shapes': [{'op': list(k), 'launches_per_step': v[0] / steps, 'ms_per_step': v[1] / steps,
+                            'TFLOPs': v[2] * v[0] / (v[1] * 1e-3) / 1e12 if v[1] and v[2] else None,
+                            'GBps': v[3] * v[0] / (v[1] * 1e-3) / 1e9 if v[1] else None} for k, v in top],
+            'note': 'HIP events around every libofx entry-point call of the eager re-run (events between calls add '
+                    'host gaps: "unattributed" = eager step time minus the brackets = torch-native copies / fills + '
+                    'gaps); kernel-symbol view: profiles/r04/*kernel_stats.csv'}
+
+
 def per_layer(prof):
     agg = {}
     for a, b, f, nb, _, shp in prof:
@@ -317,6 +458,8 @@ def per_layer(prof):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == '--cpu-worker':
+        return cpu_worker_main(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=None)
@@ -337,6 +480,16 @@ def main():
         cmd = rank_bootstrap_cmd(sys.argv[1:], args.gpus)
         sys.exit(subprocess.call(cmd))
 
+    # ONE JSON line on stdout, whatever the libraries print: RCCL writes a version banner to the C-level stdout
+    # (flushed at exit, i.e. AFTER our line).  File descriptor 1 is pointed at stderr for the life of the process and
+    # the result line is written to a private duplicate of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(real_stdout, (line + '\n').encode())
+
     from octfusion_amd import dist
     rank, local_rank, world = dist.init('gloo' if args.bootstrap_only and not torch.cuda.is_available() else None)
     if args.bootstrap_only:
@@ -348,9 +501,18 @@ def main():
             td.broadcast(t, src=0)
         mx = dist.max_over_ranks(float(rank), t.device)
         if rank == 0:
-            print(json.dumps({'bootstrap': 'ok', 'world': world, 'max_rank_seen': mx, 'shard_of_10': dist.shard_indices(10, 0, world)}))
+            emit(json.dumps({'bootstrap': 'ok', 'world': world, 'max_rank_seen': mx, 'shard_of_10': dist.shard_indices(10, 0, world)}))
         dist.barrier()
         return
+    rccl_note = None
+    if world == 1 and torch.cuda.is_available():
+        # one GPU: still run the collectives of the multi-GPU path (weight broadcast, timing reductions, barriers) through
+        # RCCL, on a one-rank group, so that a single-GPU box executes the same device path the 8-GPU run depends on
+        try:
+            dist.init(force=True)
+            rccl_note = 'one-rank nccl (RCCL) group: weight broadcast, barriers and timing reductions ran through it'
+        except Exception as e:      # noqa: BLE001
+            rccl_note = 'one-rank RCCL group could not be created (%s): collectives skipped at world 1' % e
     if world != args.gpus and rank == 0:
         print('warning: --gpus %d but WORLD_SIZE %d (reporting n_gpus = %d)' % (args.gpus, world, world), file=sys.stderr)
 
@@ -399,7 +561,7 @@ def main():
                     return wl.sampler._step(wl.net, wl.x, cond_s, wl.stage, wl.df, wl.doc, wl.nested, wl.label, self_s,
                                             coef_s, noise_s, sign, None)
                 gph = torch.cuda.CUDAGraph()
-                side_s = torch.cuda.Stream()
+                side_s = ops.side_stream(dev)
                 side_s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side_s):
                     gstep()
@@ -441,7 +603,7 @@ def main():
     dt_local = time.perf_counter() - t0
     ops.GRAPHCONV_PROFILE = None
     dt = dist.max_over_ranks(dt_local, dev)
-    rank_ms = dist.gather_floats(1e3 * dt_local / K, dev) if world > 1 else [1e3 * dt_local / K]
+    rank_ms = dist.gather_floats(1e3 * dt_local / K, dev)
     ms_step = 1e3 * dt / K
     eager_ms = None
     dt_prof = dt
@@ -452,8 +614,16 @@ def main():
         dt_prof = timed(lambda: wl.run(W + 1, K))
         ops.GRAPHCONV_PROFILE = None
         eager_ms = 1e3 * dt_prof / K
+    # per-class accounting of everything that is not the fused GraphConv: a second eager pass with an event pair
+    # around every entry-point call (kept apart from the pass above so that its brackets stay undisturbed)
+    tail, n_tail = [], max(2, min(K, 5))
+    if rank == 0 and not args.no_extras:
+        _lib.PROFILE = tail
+        dt_tail = timed(lambda: wl.run(W + 1, n_tail))
+        _lib.PROFILE = None
 
     assert bool(torch.isfinite(wl.x).all())
+    ops.raise_on_sync_error(dev)            # a flag wait of the persistent launch gave up: the timing would be void
 
     res = None
     if rank == 0:
@@ -486,20 +656,26 @@ def main():
             if os.path.exists(tpath):
                 try:
                     pj = json.load(open(tpath))
-                    if pj.get('kernel_source_sha16') == kernel_source_hash():
+                    want_k = {'fp16x3': 'gconv3_kernel<3,', 'bf16x3': 'gconv3_kernel<2,', 'fp16': 'gconv3_kernel<1,'}.get(bf)
+                    kernels = [L_.get('kernel', '') for L_ in pj.get('layers', [])]
+                    if not kernels or not all(want_k and want_k in k_ for k_ in kernels):
+                        # counters taken on another instantiation than the one this run timed say nothing about it
+                        roof['traffic_note'] = ('profiles/r04/pmc_traffic.json holds counters of %s, this run timed %s...>: '
+                                                'not reported' % (sorted(set(kernels)), want_k))
+                    elif pj.get('kernel_source_sha16') == kernel_source_hash():
                         # counters exist for four probe layers (tools/pmc_probe2.py); `traffic` is the HBM byte count
                         # of the depth-6 128 -> 128 layer, next to that layer's own algorithmic bytes
                         roof['traffic'] = pj.get('hbm_bytes_per_launch')
                         roof['traffic_layer'] = pj.get('hbm_bytes_per_launch_layer')
                         L0 = pj['layers'][0]
                         roof['traffic_layer_algorithmic_bytes'] = 4.0 * (1629600 * 128 + 217008 * 128 + 931 * 128) + 8.0 * 1629600
-                        roof['traffic_per_layer'] = [{'layer': L_['layer'], 'hbm_bytes': L_['hbm_bytes_per_launch'],
+                        roof['traffic_per_layer'] = [{'layer': L_['layer'], 'kernel': L_['kernel'], 'hbm_bytes': L_['hbm_bytes_per_launch'],
                                                       'mfma_busy_of_clocked_cycles': L_['mfma_busy_frac_of_clocked_simd_cycles'],
                                                       'clock_ghz': L_['gpu_clock_ghz_under_kernel']} for L_ in pj['layers']]
                         roof['traffic_source'] = pj.get('source')
                         roof['mfma_pmc'] = pj.get('mfma')
                     else:
-                        roof['traffic_note'] = ('profiles/r03/pmc_traffic.json was measured on kernel sources %s, this '
+                        roof['traffic_note'] = ('profiles/r04/pmc_traffic.json was measured on kernel sources %s, this '
                                                 'build is %s: not reported' % (pj.get('kernel_source_sha16'), kernel_source_hash()))
                 except Exception as e:      # noqa: BLE001
                     roof['traffic_note'] = 'pmc_traffic.json unreadable: %s' % e
@@ -508,6 +684,8 @@ def main():
                                if replay is not None else 'inside the timed region ')
                             + '(bracket includes the fused-statistics second-stage reduce and, for inputs not produced '
                             'by a GroupNorm, the multi-neighbour pre-pass)')
+        if tail:
+            res_tail = tail_summary(tail, n_tail, peak, 1e3 * dt_tail / n_tail)
         roof['all_graphconv_launches'] = graph_only
         roof['gridconv_27tap_launches'] = grid_only
         res = {
@@ -527,6 +705,7 @@ def main():
             'shape_steps_per_s': world * batch * K / dt,
             'per_rank_ms_per_step': rank_ms,
             'weight_broadcast_bytes': wl.bcast_bytes,
+            'rccl': rccl_note if world == 1 else 'nccl (RCCL) group of %d ranks' % world,
             'per_shape_setup': {'octree_and_dual_graph_ms': wl.setup_warm_ms, 'octree_and_dual_graph_first_call_ms': wl.setup_ms,
                                 'first_step_ms': first_ms, 'first_step_of_a_later_batch_ms': new_tree_first_ms,
                                 'steady_step_ms': steady_ms,
@@ -535,6 +714,8 @@ def main():
                                         'the weights'},
             'roofline': roof,
         }
+        if tail:
+            res['roofline_tail'] = res_tail
         if args.layers:
             res['layers'] = per_layer(prof)
 
@@ -598,8 +779,9 @@ def main():
         res['cpu_baseline'] = cpu_baseline(args.workload, batch)
         res['gpu_over_cpu'] = res['value'] / res['cpu_baseline']['value']
     if rank == 0:
-        print(json.dumps(res))
+        emit(json.dumps(res))
     dist.barrier()
+    dist.shutdown()
 
 
 if __name__ == '__main__':

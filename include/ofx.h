@@ -370,7 +370,12 @@ int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes,
  *        blocks as the device holds at once, each owning an equal contiguous share of the (tile, k-step) sequence;
  *        tiles cut by a share boundary are combined in-launch through `ws` (raw fp32 accumulator pieces behind the
  *        statistics partials: <= (CUs * 2) * 64 KB) and `sync`: >= (2 * CUs + 1) uint32, ZERO on the first call,
- *        left zero by every launch; word [blocks] is a sticky error flag (a bounded wait gave up).  nbr_ext needs
+ *        left zero by every launch.  The LAST word of the buffer (sync_bytes / 4 - 1, whatever the block count) is a
+ *        sticky error flag: a bounded wait gave up (several seconds: a hung or pre-empted device).  While it is set
+ *        every block of every later launch on this buffer returns at entry WITHOUT computing (a late contributor may
+ *        still store into flag words the next launch believes to be zero), so the caller must check it once per batch
+ *        of launches, clear the buffer and fall back to ofx_set_gconv_persistent(0).  One buffer (and one `ws`) per
+ *        stream: launches that may run concurrently must not share them.  nbr_ext needs
  *        16 B of readable slack behind its last entry and a 16-B aligned base.  Deterministic: the pieces of a tile
  *        are added in ascending k order.
  *      - one tile per block (sync == NULL, tiny layers, ofx_set_gconv_persistent(0)): 256 / 128 x 128 tiles, no

@@ -177,9 +177,27 @@ def _check_fresh(L):
                        % (have, sorted(want)[0] if len(want) == 1 else build.source_hash()))
 
 
+# bench.py sets PROFILE to a list to time EVERY entry-point call with HIP events on the launching stream (eager runs
+# only): entries are (name, start_event, end_event, meta); `meta` = (class, algorithmic flops, algorithmic bytes, tag)
+# set by the ops wrapper right before the call (ops._meta) or None.
+PROFILE = None
+META = None
+
+
 def call(name, *args):
     """Invoke a status-returning entry point; raise OfxError on failure."""
-    rc = getattr(lib(), name)(*args)
+    global META
+    prof = PROFILE
+    if prof is not None and _SIGS[name][2]:
+        meta, META = META, None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib(), name)(*args)
+        e1.record()
+        prof.append((name, e0, e1, meta))
+    else:
+        rc = getattr(lib(), name)(*args)
     if _SIGS[name][2] and rc != 0:
         msg = lib().ofx_status_string(rc).decode()
         raise OfxError('%s failed: %s (%d)' % (name, msg, rc))

@@ -25,7 +25,8 @@
 //     vmcnt(0) -> barrier -> one relaxed agent-scope flag store | one lane polls relaxed -> ONE agent-scope acquire ->
 //     barrier -> plain loads).  No block ever waits on a block that can itself be waiting (contributors' pieces are
 //     their first work item and depend on nothing), so the launch cannot deadlock as long as blocks are dispatched in
-//     index order; a spin is bounded all the same and reports through flags[G].
+//     index order; a spin is bounded all the same and reports through the sticky word Gemm3Args::err, which
+//     makes every later launch on the same sync buffer return at entry until the host has cleared it.
 // Range boundaries are snapped so that no piece is shorter than G3_KMIN k-steps: the loop shape is always
 // {steady..., last steady (requests the epilogue operands), drain A, drain B}.
 #include "ofx_planes.h"
@@ -50,7 +51,12 @@ struct Gemm3Args {
   unsigned U;                  // units of the stream-K region (its tiles * nkt)
   int dp_rounds;               // whole-tile rounds in front of it: tile r * G + lb belongs to block lb
   float* part;                 // [G][BM * BN] raw accumulator pieces
-  unsigned* flags;             // [G + 1], zero on entry and on exit; flags[G] != 0: a spin gave up
+  unsigned* flags;             // [G], zero on entry and on exit
+  unsigned* err;               // sticky error word (the LAST word of the caller's sync buffer, whatever G is): != 0 once a
+                               // bounded wait gave up.  Every block of every later launch returns at entry while it is
+                               // set: a contributor that was late once may still store its flag into a buffer the next
+                               // launch believes to be zero, so nothing may wait on these words again until the host
+                               // has noticed (ops.raise_on_sync_error), cleared them and switched launch shape
   const char* nbr_lim;         // last 16-B aligned address inside nbr_ext that may be read
   int snap;                    // 1: share boundaries snapped to the nearest legal cut position, 0: towards the tile boundary (A/B)
   int early;                   // every share spans >= one tile (a tile is cut at most once, and its second piece is
@@ -104,6 +110,8 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
   unsigned long long ts0 = 0, ts1 = 0;
   int dbg_piece = 0;
   if (dbg) ts0 = g2_clock();
+  // a wait of an EARLIER launch on this sync buffer gave up: its flags can no longer be trusted (see Gemm3Args::err)
+  if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return;
 
   // ---- wave-uniform operands pinned in SGPRs (a kernarg s_load sunk into the loop would mix SMEM events into the
   // hand-counted lgkmcnt waits)
@@ -399,7 +407,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
         while (__hip_atomic_load(flags_s + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
           __builtin_amdgcn_s_sleep(8);
           if (g2_clock() - tstart > (1ull << 33)) {                     // several seconds: give up, report, go on
-            __hip_atomic_store(flags_s + G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
         }
@@ -788,6 +796,7 @@ int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, siz
   A.b = a;
   A.G = p.G; A.q = p.q; A.rem = p.rem; A.U = p.U; A.dp_rounds = p.dp_rounds;
   A.part = (float*)ws_tail; A.flags = (unsigned*)sync;
+  A.err = (unsigned*)sync + (sync_bytes / sizeof(unsigned) - 1);
   A.snap = g3_snap;
   // (shares of >= one tile: boundaries are >= nkt apart and snapping only ever moves one ONTO a tile boundary, so a
   // tile has at most one interior cut; its second piece is its block's first work, published ~a tile before the

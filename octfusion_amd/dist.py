@@ -16,9 +16,37 @@ def env_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+def _active(force=False):
+    """Is there a process group whose collectives should run?  World size 1 short-circuits every helper below unless
+    `force` (or a group that was created with init(force=True)): then the one-rank collective really goes through the
+    backend -- RCCL on a GPU box -- which is how the device path of this module is exercised on a single MI355X
+    (tests/test_gpu_dist.py, `bench.py --gpus 1`)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or force or _FORCED
+
+
+_FORCED = False
+
+
+def init(backend=None, force=False):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1 unless `force`: then a
+    one-rank group is created on 127.0.0.1 and every helper of this module runs its collective through it)."""
+    global _FORCED
     rank, local_rank, world = env_world()
+    if force and world == 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        import socket
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+        _FORCED = True
+        return rank, local_rank, world
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'      # "nccl" is RCCL on ROCm
@@ -36,9 +64,9 @@ def shard_indices(n_items, rank, world):
 
 
 @torch.no_grad()
-def broadcast_module_(module, src=0):
+def broadcast_module_(module, src=0, force=False):
     """Broadcast every parameter and buffer of `module` from `src` as ONE flat fp32 buffer."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active(force):
         return 0
     # the parameters themselves (not .data, which has its own version counter): copy_ below bumps _version, which is
     # what the packed-weight caches key on -- a forward that ran before the broadcast cannot leave stale packs
@@ -62,31 +90,49 @@ def broadcast_module_(module, src=0):
     return total * 4
 
 
+def _pg_device():
+    """Device a collective's tensors must live on for the default process group (RCCL: this rank's GPU)."""
+    if dist.get_backend() == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+_VERIFIED_SETS = set()
+
+
+def _check_gradient_set(grads, keys):
+    """Ranks with different key sets / sizes would pack different flat buckets: an RCCL hang or silent corruption.
+    ONE tiny all-reduce -- MAX over [sig, -sig], i.e. max and min at once -- of (key count, total elements, a checksum
+    over every `name:numel` pair) turns that into an error.  A set that was verified once is not checked again (the
+    parameters of a model do not change between steps): the check costs a collective + a host read only on the first
+    step and when the set changes."""
+    import zlib
+    ident = tuple((k, grads[k].numel()) for k in keys)
+    if ident in _VERIFIED_SETS:
+        return
+    sig = [len(keys), sum(n for _, n in ident), sum(zlib.crc32(('%s:%d' % kn).encode()) for kn in ident) % (1 << 40)]
+    t = torch.tensor(sig + [-v for v in sig], dtype=torch.int64, device=_pg_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    hi, lo = t[:3].tolist(), [-v for v in t[3:].tolist()]
+    if hi != lo:
+        raise RuntimeError('all_reduce_mean_: the ranks hold different gradient sets (keys / sizes: min %s, max %s) -- a '
+                           'parameter without gradient on some rank must be zero-filled by the caller' % (lo, hi))
+    _VERIFIED_SETS.add(ident)
+
+
 @torch.no_grad()
-def all_reduce_mean_(grads, bucket_bytes=256 << 20):
+def all_reduce_mean_(grads, bucket_bytes=256 << 20, force=False):
     """Data-parallel training (the reference wraps its nets in DistributedDataParallel: octfusion_model_union.py:185-196,
     octfusion_model_vae.py:121-130): average the gradient dict over the ranks in place.  Gradients are packed, in
     sorted key order, into flat fp32 buckets of up to `bucket_bytes` -- a few large ring all-reduces (per-link bound on
     xGMI, so size matters more than count) instead of one per tensor.  Every rank must hold the same keys; a key that
     is missing on some rank (a parameter without gradient there) is an error the caller has to resolve.
     Returns the number of bytes reduced."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active(force):
         return 0
     world = dist.get_world_size()
     keys = sorted(grads)
-    # ranks with different key sets / sizes would pack different flat buckets: an RCCL hang or silent corruption.
-    # One tiny all-reduce of (key count, total elements, a key-name checksum) turns that into an error.
-    import zlib
-    dev = grads[keys[0]].device if keys else torch.device('cpu')
-    sig = torch.tensor([len(keys), sum(grads[k].numel() for k in keys),
-                        sum(zlib.crc32(k.encode()) for k in keys) % (1 << 40)], dtype=torch.int64, device=dev)
-    lo, hi = sig.clone(), sig.clone()
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    if not torch.equal(lo, hi):
-        raise RuntimeError('all_reduce_mean_: the ranks hold different gradient sets (keys / sizes: min %s, max %s) -- a '
-                           'parameter without gradient on some rank must be zero-filled by the caller'
-                           % (lo.tolist(), hi.tolist()))
+    _check_gradient_set(grads, keys)
     total = 0
     bucket, size = [], 0
 
@@ -114,18 +160,18 @@ def all_reduce_mean_(grads, bucket_bytes=256 << 20):
     return total
 
 
-def max_over_ranks(value, device):
+def max_over_ranks(value, device, force=False):
     """MAX all-reduce of a python float (timing)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active(force):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def gather_floats(value, device):
+def gather_floats(value, device, force=False):
     """[value of rank 0, ..., value of rank W-1] on every rank (per-rank step times)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active(force):
         return [value]
     t = torch.tensor([value], dtype=torch.float64, device=device)
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
@@ -133,6 +179,14 @@ def gather_floats(value, device):
     return [float(o.item()) for o in out]
 
 
-def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+def barrier(force=False):
+    if _active(force):
         dist.barrier()
+
+
+def shutdown():
+    """Destroy the process group (tests that create a forced one-rank group)."""
+    global _FORCED
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+    _FORCED = False

@@ -89,6 +89,8 @@ def generate(net, cfg, n_shapes, rank, world, seed=0, ddim_steps=200, label=None
                         timings=timings)
         if dev.type == 'cuda':
             torch.cuda.synchronize()
+            from . import ops
+            ops.raise_on_sync_error(dev)         # (the DDIM loops check per stage; this covers the VAE decode)
         dt = time.perf_counter() - t0
         if out_dir is not None:
             write_outputs(out_dir, idxs, out, cfg)
@@ -98,12 +100,21 @@ def generate(net, cfg, n_shapes, rank, world, seed=0, ddim_steps=200, label=None
 def write_outputs(out_dir, idxs, out, cfg):
     """Per shape: <index>/split_small.pth (+ split_large.pth) in the reference's sample-file format
     (tools/gen_split.py:50-54), and <index>/sdf.pt when the SDF lattice was computed."""
-    from .octree import octree2split_small
+    from .octree import octree2split_large, octree2split_small
     small = octree2split_small(out['octree_small'], cfg['full_depth'])
+    large = bid = None
+    if 'octree_large' in out:
+        # depth-8 cascade (3-stage model): the stage-2 sample format, one [nnum6 of the shape, 8] tensor per shape
+        # (gen_split.py:50-54 writes it from a one-shape octree; here the batch is sliced by the depth-6 batch ids)
+        sd = cfg['input_depth'][1]
+        large = octree2split_large(out['octree_large'], sd)
+        bid = out['octree_large'].batch_id(sd)
     for b, i in enumerate(idxs):
         d = os.path.join(out_dir, str(i))
         os.makedirs(d, exist_ok=True)
         torch.save(small[b].cpu(), os.path.join(d, 'split_small.pth'))
+        if large is not None:
+            torch.save(large[bid == b].cpu(), os.path.join(d, 'split_large.pth'))
         if 'sdfs' in out:
             torch.save(out['sdfs'][b].cpu(), os.path.join(d, 'sdf.pt'))
 

@@ -19,6 +19,13 @@ ACT = {None: 0, 'none': 0, 'silu': 1, 'gelu': 2}
 GRAPHCONV_PROFILE = None
 
 
+def _meta(kind, flops=0.0, nbytes=0.0, tag=None):
+    """Label the NEXT _lib.call for bench.py's per-class tail accounting (_lib.PROFILE): class, ALGORITHMIC flops and
+    bytes of the launch (what the operator has to compute / move, not what the kernel happens to), a shape tag."""
+    if _lib.PROFILE is not None:
+        _lib.META = (kind, float(flops), float(nbytes), tag)
+
+
 def _chk(t, dtype=torch.float32):
     if t is None:
         return
@@ -148,6 +155,7 @@ def planes_split(x, mode, Cpad=None, out=None):
     ch = _planes_chunk(mode)
     Cpad = Cpad if Cpad is not None else (C + ch - 1) // ch * ch
     out, ldo = _planes_out(n, Cpad, mode, x.device, out)
+    _meta('planes_split', 0, 4.0 * n * C + (4.0 if planes_pairs(mode) else 2.0) * n * Cpad, (n, C, Cpad))
     call('ofx_planes_split', ptr(x), ldx, n, C, Cpad, mode, ptr(out), ldo, stream())
     setattr(out, PLANES_ATTR, mode)
     return out
@@ -234,6 +242,8 @@ def graphconv_planes(xp, mode, seg_ptr, col, ext, pw, cin, nt, tf_planes=None, b
         e0.record()
     ws = workspace(xp.device)
     sync = sync_words(xp.device)
+    _meta('graphconv', 2.0 * N * pw.K * pw.N, 0, (N, pw.cin, pw.N, 'planes', 'emb' if emb is not None else '',
+                                                  'res' if res is not None else '', 'stats' if stats is not None else ''))
     call('ofx_graphconv_fwd_planes', ptr(xp), ldx, cin, N, ptr(seg_ptr), ptr(col), ptr(nbr_ext), ptr(multi_seg),
          n_multi, ptr(aux), aux.numel() * aux.element_size(), ptr(tf_planes), ldt, nt, ptr(pw.t), pw.N, ptr(bias),
          ptr(emb), lde, ptr(batch_id) if (emb is not None or stats is not None) else None, ptr(res), ldr, ptr(out),
@@ -267,10 +277,16 @@ _SYNC = {}
 SYNC_WORDS = 4096
 
 
+def _stream_id(device):
+    return torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
+
+
 def sync_words(device):
-    """Per-device flag words of the persistent stream-K GraphConv (include/ofx.h): zero at allocation, every launch
-    leaves them zero; the word behind the last block's flag is a sticky error flag (sync_error())."""
-    key = (device.type, device.index)
+    """Flag words of the persistent stream-K GraphConv (include/ofx.h), one buffer per (device, STREAM): launches on
+    one stream are ordered and may share them, launches on different streams (or graphs captured on different streams)
+    run concurrently and must not.  Zero at allocation, every launch leaves them zero; the LAST word is the sticky
+    error flag (sync_error())."""
+    key = (device.type, device.index, _stream_id(device))
     t = _SYNC.get(key)
     if t is None:
         t = _SYNC[key] = torch.zeros(SYNC_WORDS, dtype=torch.int32, device=device)
@@ -278,16 +294,28 @@ def sync_words(device):
 
 
 def sync_error(device):
-    """True if a bounded wait of a persistent launch on `device` ever gave up (host sync; tests / smoke only)."""
-    t = _SYNC.get((device.type, device.index))
-    return bool(t is not None and int(t.abs().sum().item()) != 0)
+    """True if a bounded wait of a persistent launch on `device` ever gave up, or a launch left a flag set (host sync)."""
+    return any(int(t.abs().sum().item()) != 0 for k, t in _SYNC.items() if k[:2] == (device.type, device.index))
+
+
+def raise_on_sync_error(device):
+    """Production check, once per sampling call (sampler.sample_loop, generate, bench): a bounded wait of the persistent
+    GraphConv launch gave up -> the results since then are invalid.  Clears the words, switches this process to the
+    one-tile-per-block launch (no inter-block waits) and raises."""
+    if not _SYNC or not sync_error(device):
+        return
+    for k, t in _SYNC.items():
+        if k[:2] == (device.type, device.index):
+            t.zero_()
+    call('ofx_set_gconv_persistent', 0)
+    raise _lib.OfxError('a flag wait of the persistent GraphConv launch gave up on %s: the results of this call are '
+                        'invalid; the process now uses the one-tile-per-block launch (ofx_set_gconv_persistent(0))' % device)
 
 
 def workspace(device, nbytes=96 << 20):
-    """Per-device split-K scratch (partial tiles); reused by every launch -- launches are ordered on one stream.  Only
-    with the side-stream experiment on (two streams run concurrently) it is kept per stream."""
-    sid = torch.cuda.current_stream(device).cuda_stream if (SIDE_STREAM and device.type == 'cuda') else 0
-    key = (device.type, device.index, sid)
+    """Split-K / partial-tile scratch, one buffer per (device, stream): launches on one stream are ordered and reuse it,
+    launches on different streams (side-stream experiment, graphs captured on their own stream) must not share it."""
+    key = (device.type, device.index, _stream_id(device))
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -360,6 +388,8 @@ def gemm(a, pw, bias=None, res=None, out=None, a_rows=None, out_rows=None, m=Non
     _chk(a_rows, torch.int32)
     _chk(out_rows, torch.int32)
     ws = workspace(a.device)
+    _meta('dense_gemm', 2.0 * M * pw.K * pw.N, 4.0 * (M * pw.K + pw.K * pw.N + M * pw.N * (2 if res is not None else 1)),
+          (M, pw.K, pw.N))
     args = ('ofx_gemm_f32', ptr(a), lda, ptr(a_rows), M, pw.K, ptr(pw.t), pw.Kp, pw.N, ptr(bias),
             ptr(res), ldr, ptr(out), ldc, ptr(out_rows), ptr(ws), ws.numel(), stream())
     if pw.N <= 64 or pw.K <= 64:
@@ -424,6 +454,7 @@ def graphconv(x, nbr, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None
             ptr(pw.t), pw.Kp, pw.N, ptr(bias), ptr(emb), lde,
             ptr(batch_id) if (emb is not None or stats is not None) else None,
             ptr(res), ldr, ptr(out), ldc, ptr(stats), pw.N, ptr(ws), ws.numel(), stream())
+    _meta('graphconv', 2.0 * N * pw.K * pw.N, 0, (N, cin, pw.N, 'reg'))
     if pw.N <= 64 or cin <= 64:
         with policy_scope('small_gemm'):
             call(*args)
@@ -573,6 +604,9 @@ def gridconv(x, tables, n_out, pw, bias=None, emb=None, batch_id=None, res=None,
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
+    _meta('gridconv_27tap', 2.0 * n_out * 27 * pw.cin * pw.N,
+          4.0 * (x.shape[0] * pw.cin + n_out * pw.N * (2 if res is not None else 1) + 27.0 * pw.cin * pw.N) + 4.0 * 27 * n_out,
+          (n_out, pw.cin, pw.N))
     call('ofx_gridconv_fwd', ptr(x), ldx, pw.cin, x.shape[0], n_out, None if fast else ptr(tables(False)),
          ptr(tables(True)) if fast else None, ptr(zero_row(x.device)), ptr(pw.t), pw.N, ptr(bias), ptr(emb), lde,
          ptr(batch_id) if emb is not None else None, ptr(res), ldr, ptr(out), ldc, ptr(ws), ws.numel(), stream())
@@ -600,6 +634,7 @@ def attention(qkv, batch_size, T, heads, out=None):
         out = torch.empty(qkv.shape[0], C, dtype=torch.float32, device=qkv.device)
     out2, ldo = _row_major(out)
     assert out2 is out
+    _meta('attention', 4.0 * batch_size * heads * T * T * ch, 4.0 * qkv.shape[0] * 4 * C, (batch_size, T, heads, ch))
     call('ofx_attention', ptr(qkv), ldq, batch_size, T, heads, ch, ptr(out), ldo, stream())
     return out
 
@@ -647,6 +682,7 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
             out = torch.empty(n, C, dtype=torch.float32, device=dev)
         out2, ldo = _row_major(out)
         assert out2 is out
+        _meta('gn_fused_rows', 0, 8.0 * n * C, (n, C))
         call('ofx_gn_fused_rows', ptr(x), ldx, rows_per_batch, batch_size, C, groups, eps, count_eps,
              ptr(weight.detach().reshape(-1)), ptr(bias.detach().reshape(-1)), ACT[act], ptr(out), ldo, stream())
         return out
@@ -656,6 +692,7 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         sums = stats
     else:
         sums = torch.empty(batch_size * C * 2, dtype=torch.float64, device=dev)
+        _meta('gn_stats', 0, 4.0 * n * C, (n, C))
         call('ofx_gn_stats', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
     # mean / rstd are derived from the sums inside the apply launch (ofx.h: no ofx_gn_finalize launch) -- except when
     # the launch also writes the consuming GraphConv's aux rows: those blocks normalise scattered source rows of any
@@ -666,6 +703,7 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
     if GN_FINALIZE_LAUNCH or (planes and aux_graph is not None):
         mean = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
         rstd = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
+        _meta('gn_finalize', 0, 24.0 * batch_size * C, (batch_size, C))
         call('ofx_gn_finalize', ptr(sums), ptr(count), batch_size, C, groups, eps, count_eps, ptr(mean), ptr(rstd),
              stream())
     w = weight.detach().reshape(-1)
@@ -682,6 +720,7 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         if aux_graph is not None:
             seg_ptr, col, multi_seg, n_multi = aux_graph
             aux = torch.empty((n_multi + 1) * ldo, dtype=torch.uint8, device=dev)
+        _meta('gn_apply', 0, 8.0 * n * C + (n_multi + 1) * float(ldo), (n, C, 'planes+aux' if aux is not None else 'planes'))
         call('ofx_gn_apply_planes', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(sums), ptr(count), groups, eps,
              count_eps, ptr(w), ptr(b), ACT[act], planes, ptr(out), ldo, ptr(seg_ptr), ptr(col), ptr(multi_seg), n_multi,
              ptr(aux), stream())
@@ -693,6 +732,7 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         out = torch.empty(n, C, dtype=torch.float32, device=dev)
     out2, ldo = _row_major(out)
     assert out2 is out
+    _meta('gn_apply', 0, 8.0 * n * C, (n, C, 'fp32'))
     call('ofx_gn_apply', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(sums), ptr(count), groups, eps, count_eps,
          ptr(w), ptr(b), ACT[act], ptr(out), ldo, stream())
     return out
@@ -796,6 +836,7 @@ def rows_copy(src, dst, n, smap=None, dmap=None, C=None):
     dst2, ldd = _row_major(dst)
     assert dst2 is dst
     C = C if C is not None else src.shape[1]
+    _meta('rows_copy', 0, 8.0 * n * C, (n, C))
     call('ofx_rows_copy', ptr(src), lds, ptr(smap), ptr(dst), ldd, ptr(dmap), n, C, stream())
     return dst
 
@@ -805,6 +846,7 @@ def act(x, kind, out=None):
     x = x.contiguous()
     if out is None:
         out = torch.empty_like(x)
+    _meta('elementwise', 0, 8.0 * x.numel(), (x.numel(),))
     call('ofx_act', ptr(x), ptr(out), x.numel(), ACT[kind], stream())
     return out
 
@@ -841,6 +883,7 @@ def voxel2octree_cf(vox, depth, out=None):
 def ddim_eps_update(x, eps, coef, x0_out=None):
     _chk(x), _chk(eps), _chk(coef), _chk(x0_out)
     assert x.is_contiguous() and eps.is_contiguous()
+    _meta('elementwise', 0, 12.0 * x.numel(), (x.numel(),))
     call('ofx_ddim_eps_update', ptr(x), ptr(eps), ptr(coef), ptr(x0_out), x.numel(), stream())
     return x
 
@@ -848,5 +891,6 @@ def ddim_eps_update(x, eps, coef, x0_out=None):
 def ddim_x0_update(x, x0, noise, coef):
     _chk(x), _chk(x0), _chk(coef)
     assert x.is_contiguous() and x0.is_contiguous()
+    _meta('elementwise', 0, 16.0 * x.numel(), (x.numel(),))
     call('ofx_ddim_x0_update', ptr(x), ptr(x0), ptr(noise), ptr(coef), x.numel(), stream())
     return x

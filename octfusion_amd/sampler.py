@@ -127,7 +127,7 @@ def sample_loop(net, shape, batch_size, ddim_steps, unet_type, df_type, device, 
                     st['self'] if key[2] else None, c, st['noise'] if key[1] else None, do_sign, x0_buf)
             g = torch.cuda.CUDAGraph()
             keep = x.clone()
-            side = torch.cuda.Stream()
+            side = ops.side_stream(x.device)                 # ONE warm-up stream per device: scratch is kept per stream
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 _step(*args)                           # warm-up of this regime outside the capture
@@ -141,4 +141,6 @@ def sample_loop(net, shape, batch_size, ddim_steps, unet_type, df_type, device, 
         c.copy_(coef)
         g.replay()
         x_start = res
+    if x.is_cuda:
+        ops.raise_on_sync_error(x.device)       # (one host read per stage; the caller synchronises right after anyway)
     return x

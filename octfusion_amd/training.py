@@ -28,7 +28,8 @@ class AdamW:
         in DistributedDataParallel does at construction for the reference, octfusion_model_union.py:185-196) -- ranks
         that were seeded differently would otherwise average gradients of different models, silently."""
         import torch.distributed as td
-        if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        from . import dist as D
+        if not D._active():
             return 0
         keys = sorted(self.params)
         tensors = [self.params[k].data for k in keys] + [s for k in keys for s in self.state[k]]

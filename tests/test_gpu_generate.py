@@ -80,3 +80,28 @@ def test_batched_shapes_draw_the_reference_per_shape_noise():
         torch.cuda.manual_seed(seed)
         want = torch.randn((doc1.total_num, 3), device=dev())
         assert torch.equal(init[bid == b], want)
+
+
+def test_write_outputs_keeps_the_depth8_cascade_readable(tmp_path):
+    """generate.write_outputs on a 3-stage result: <i>/split_large.pth per shape (tools/gen_split.py:50-54), which
+    checkpoint.read_splits + split2octree_large turn back into the same depth-8 octree, shape by shape."""
+    from octfusion_amd import checkpoint, configs, generate as G, synthetic
+    from octfusion_amd.octree import split2octree_large, split2octree_small
+    cfg = configs.CONFIGS['obja_uncond']
+    split = synthetic.shell6_split(2, jitter=True).to(dev())
+    oc6 = split2octree_small(split, 6, 4)
+    x6, y6, z6, _ = oc6.xyzb(6)
+    oc8 = split2octree_large(oc6, synthetic.shell8_split_large(x6.cpu(), y6.cpu(), z6.cpu()).to(dev()), 6)
+    out_dir = str(tmp_path / 'gen3')
+    G.write_outputs(out_dir, [7, 3], {'octree_small': oc6, 'octree_large': oc8}, cfg)
+    for b, i in enumerate([7, 3]):
+        small, large = checkpoint.read_splits(os.path.join(out_dir, str(i)), dev())
+        assert large is not None and large.shape[1] == 8 and set(large.unique().tolist()) <= {-1.0, 1.0}
+        one6 = split2octree_small(small, 6, 4)
+        assert large.shape[0] == int(one6.nnum[6])
+        one8 = split2octree_large(one6, large, 6)
+        ref6 = split2octree_small(split[b:b + 1], 6, 4)
+        xr, yr, zr, _ = ref6.xyzb(6)
+        ref8 = split2octree_large(ref6, synthetic.shell8_split_large(xr.cpu(), yr.cpu(), zr.cpu()).to(dev()), 6)
+        for d in (7, 8):
+            assert torch.equal(one8.keys[d], ref8.keys[d]) and torch.equal(one8.children[d], ref8.children[d])

@@ -18,11 +18,13 @@ ops.PLANES_MIN_TILES = 1
 for d, cin, cout in [(6, 128, 128), (5, 256, 256), (6, 384, 128), (5, 512, 512)]:
     N = doc.csr(d)[2]
     conv = M.GraphConv(cin, cout, 7, 7, d - 1).to(dev)
-    conv.emit_stats = False
+    # the instantiation the bench runs: default precision (fp16 pairs -> gconv3_kernel<3, ...>), fused statistics ON
+    assert conv.emit_stats and ops.get_precision() == ops.DEFAULT_PRECISION
     gn = M.DualOctreeGroupNorm(cin).to(dev)
-    xp = gn(torch.randn(N, cin, device=dev), doc, d, act='silu', planes=2)      # planes + aux rows (no pre-pass launch)
+    xp = gn(torch.randn(N, cin, device=dev), doc, d, act='silu', planes=ops.planes_mode())   # planes + aux rows (no pre-pass launch)
     res = torch.randn(N, cout, device=dev)
     emb = torch.randn(8, cout, device=dev)
     for _ in range(4):
-        conv(xp, doc, d, emb=emb, res=res)
+        with ops.stats_scope(dev):
+            conv(xp, doc, d, emb=emb, res=res)
 torch.cuda.synchronize()

@@ -1,4 +1,4 @@
-"""Summarise the rocprofv3 --pmc passes over tools/pmc_probe2.py into profiles/r03/pmc_traffic.json.
+"""Summarise the rocprofv3 --pmc passes over tools/pmc_probe2.py into profiles/r04/pmc_traffic.json.
 
     python tools/pmc_summary.py <dir with <pass>/p_counter_collection.csv> <out.json>
 Passes (one rocprofv3 run each: counters of different blocks do not share a pass reliably):
@@ -38,8 +38,8 @@ for f in ('ofx_gemm3.hip', 'ofx_planes.h', 'ofx_gemm2.hip', 'ofx_gemm.hip', 'ofx
     h.update(open(os.path.join(ROOT, 'octfusion_amd', 'csrc', f), 'rb').read())
 out = {'kernel_source_sha16': h.hexdigest()[:16], 'workload': 'hr',
        'source': 'rocprofv3 --pmc, one pass per counter group, over tools/pmc_probe2.py on MI355X: 4 launches per layer '
-                 'of gconv3_kernel (persistent planes GraphConv with emb + residual epilogue), shell-6 B=8; raw rows '
-                 'in profiles/r03/pmc_*_probe2.csv',
+                 'of gconv3_kernel (persistent planes GraphConv, default fp16-pair instantiation, emb + residual + fused statistics epilogue), shell-6 B=8; raw rows '
+                 'in profiles/r04/pmc_*_probe2.csv',
        'fetch_correction': 'HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB)',
        'clock_note': 'GRBM_GUI_ACTIVE is summed over the 8 XCDs: clock = counter / 8 / kernel duration', 'layers': []}
 for L in LAYERS:
@@ -56,10 +56,11 @@ for L in LAYERS:
         'hbm_bytes_per_launch': 1024.0 * (2 * mean(d['FETCH_SIZE']) + mean(d['WRITE_SIZE'])),
         'launch_us_in_sq_pass': ns / 1e3, 'mfma_busy_cycles': busy, 'gpu_clock_ghz_under_kernel': clk,
         'mfma_busy_frac_of_clocked_simd_cycles': busy / (1024 * clk * ns), 'mfma_busy_frac_at_2.4GHz': busy / (1024 * 2.4 * ns),
-        'mfma_ideal_cycles_bf16x3': flops * 3 / (2 * 32 * 32 * 16) * 32,
+        'mfma_ideal_cycles_three_term': flops * 3 / (2 * 32 * 32 * 16) * 32,
         'wave_cycle_split': {'issuing': mean(d['SQ_ACTIVE_INST_ANY']) / wc, 'stalled_at_issue': mean(d['SQ_WAIT_INST_ANY']) / wc,
                              'parked_waitcnt_or_barrier': mean(d['SQ_WAIT_ANY']) / wc},
         'lds_bank_conflict_cycles': mean(d['SQ_LDS_BANK_CONFLICT']), 'lds_idx_active_cycles': mean(d['SQ_LDS_IDX_ACTIVE'])})
+out['kernels'] = sorted({L_['kernel'] for L_ in out['layers']})
 first = out['layers'][0]
 out['hbm_bytes_per_launch'] = first['hbm_bytes_per_launch']
 out['hbm_bytes_per_launch_layer'] = first['layer']

@@ -45,6 +45,25 @@ int ofx_device_check(void);
 const char* ofx_build_hash(void);
 int ofx_build_ablation(void);
 
+/* ------------------------------------------------------------------ fp16x3 range guard (precision 3, the default)
+ * Operands travel as fp16 hi + lo pairs (22 significand bits).  What that covers and what it does not:
+ *  - WEIGHTS are scaled at pack time by a per-tensor power of two so that max|w| lands in [2^14, 2^15) (the kernels
+ *    multiply the accumulators by the inverse in the epilogue FMA that adds the bias anyway -- exact, free): every
+ *    weight within 2^-18 of the tensor's largest keeps 22 bits, smaller ones an ABSOLUTE error of 2^-40 max|w| --
+ *    fp32-class against the output whatever the tensor's own magnitude (a near-zero-initialised projection that
+ *    learned 1e-4-scale weights is as exact as an O(1) one);
+ *  - ACTIVATIONS are not scaled.  Below |x| ~ 2^-3 the lo half is a denormal fp16: an absolute error floor of
+ *    2^-25 ~ 3e-8 per operand (relative 2^-22 above it).  Normalised activations (every GraphConv input that comes
+ *    from a GroupNorm) are O(1): there the floor is fp32's own.  Beyond +-65504 an operand does NOT saturate: its
+ *    halves become +-Inf and every product it enters is NaN, so an un-normalised operand outside the range (network
+ *    inputs, pool / unpool outputs, the residual stream into the 1x1 skip convolutions) makes the result loudly
+ *    non-finite instead of plausibly wrong.  words[0] += the operands ofx_planes_split found outside the range
+ *    (exact count, diagnostics).  The caller checks finiteness of a stage's result and the word once per batch of
+ *    launches (octfusion_amd.ops.raise_on_range_error) and re-runs in bf16x3 (precision 0: fp32's exponent range,
+ *    16 significand bits).
+ * ofx_set_range_words: device pointer to >= 4 zeroed uint32 on the CURRENT device (NULL: counting off).  Sticky. */
+int ofx_set_range_words(uint32_t* words);
+
 /* ------------------------------------------------------------------ scans */
 /* Exclusive prefix sum of n int32 values into out[0..n] (out[n] = total).
  * ws: workspace of at least ofx_scan_ws_bytes(n) bytes.

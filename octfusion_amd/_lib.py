@@ -89,6 +89,7 @@ _SIGS = {
     'ofx_graph_expand': (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_p], True),
     'ofx_graph_type_frac': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_l, c_p], True),
     'ofx_set_precision': (c_i, [c_i], True),
+    'ofx_set_range_words': (c_i, [c_p], True),
     'ofx_get_precision': (c_i, [], False),
     'ofx_packed_floats': (c_l, [c_l, c_l], False),
     'ofx_packed_k': (c_l, [c_l], False),

@@ -26,6 +26,9 @@ static inline bool ofx_raise_lds_limit(const void* kernel, int bytes, bool (&don
   return true;
 }
 
+// fp16x3 range guard (include/ofx.h): per-device pointer to the caller's sticky words, or NULL.  Defined in ofx_misc.hip.
+uint32_t* ofx_range_words();
+
 // grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8.
 static inline int ofx_grid(int64_t work_items, int block) {
   int64_t g = ofx_cdiv(work_items, block);

@@ -548,8 +548,8 @@ __device__ __forceinline__ void split_bf16x4(const float4& v, uint2& hi, uint2& 
   lo.y = cvt_pk_bf16(v.z - hz, v.w - hw);
 }
 // H16 = 0: bf16 pairs ("bf16x3"); 1: fp16 pairs ("fp16x3": 11 + 11 significand bits, same three MFMAs per product --
-// v_mfma_f32_32x32x16_f16 honours fp16 denormals, so the lo part stays exact down to 2^-24; values saturate at the
-// fp16 range).  See ofx_planes.h for the formats.
+// v_mfma_f32_32x32x16_f16 honours fp16 denormals, so the lo part stays exact down to 2^-24; values beyond the fp16
+// range turn into Inf / NaN, see split16x4).  See ofx_planes.h for the formats.
 __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
   const _Float16 x = (_Float16)a, y = (_Float16)b;
   return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
@@ -562,7 +562,10 @@ __device__ __forceinline__ void split16x4(const float4& v, uint2& hi, uint2& lo)
   if constexpr (H16 == 0) {
     split_bf16x4(v, hi, lo);
   } else {
-    const float x = sat_f16(v.x), y = sat_f16(v.y), z = sat_f16(v.z), w = sat_f16(v.w);
+    // NO saturation: an operand beyond +-65504 becomes hi = +-Inf, lo = -+Inf, and the products poison the output
+    // with NaN -- a loud failure the caller's finiteness check turns into a bf16x3 retry (include/ofx.h, range guard),
+    // instead of a silently clamped, plausible-looking result
+    const float x = v.x, y = v.y, z = v.z, w = v.w;
     hi.x = cvt_pk_f16(x, y);
     hi.y = cvt_pk_f16(z, w);
     lo.x = cvt_pk_f16(x - f16_lo_f32(hi.x), y - f16_hi_f32(hi.x));
@@ -871,6 +874,9 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {
 __global__ void pack_bf16x3_kernel(const float* __restrict__ Wp, int64_t Kp, int64_t N, uint16_t* __restrict__ W16,
                                    int h16) {
   const int64_t total = Kp * N;            // one element per (k, n)
+  // per-tensor power-of-two scale of the fp16 halves (trailer behind the 16-bit planes, weight_scale_kernel): the
+  // epilogues multiply the accumulators by its inverse (GemmArgs::oscale_p; include/ofx.h, range guard)
+  const float wscale = h16 ? reinterpret_cast<const float*>(W16 + 2 * total)[1] : 1.f;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t kg = t / (N * 8), rem = t - kg * N * 8;
     const int64_t n = rem / 8;
@@ -878,7 +884,7 @@ __global__ void pack_bf16x3_kernel(const float* __restrict__ Wp, int64_t Kp, int
     const int64_t k = kg * 8 + kk;
     const float w = Wp[((k >> 2) * N + n) * 4 + (k & 3)];
     if (h16) {                             // fp16 pairs (precision 3)
-      const float ws = sat_f16(w);
+      const float ws = sat_f16(w * wscale);
       const _Float16 hi = (_Float16)ws;
       const _Float16 lo = (_Float16)(ws - (float)hi);
       W16[t] = __builtin_bit_cast(unsigned short, hi);
@@ -897,6 +903,8 @@ static int g_precision = 3;
 // after ofx_set_precision
 static int pack_bf16x3(const float* Wp, int64_t Kp, int64_t N, hipStream_t st) {
   uint16_t* W16 = reinterpret_cast<uint16_t*>(const_cast<float*>(Wp) + Kp * N);
+  weight_scale_kernel<<<1, 1024, 0, st>>>(Wp, 1, 0, Kp * N, 1, g_precision == 3 ? 1 : 0,
+                                          const_cast<float*>(Wp) + 2 * Kp * N);
   pack_bf16x3_kernel<<<ofx_grid(Kp * N, 256), 256, 0, st>>>(Wp, Kp, N, W16, g_precision == 3 ? 1 : 0);
   return OFX_OK;
 }
@@ -912,7 +920,8 @@ extern "C" int ofx_set_precision(int mode) {
   return OFX_OK;
 }
 extern "C" int ofx_get_precision(void) { return g_precision; }
-extern "C" int64_t ofx_packed_floats(int64_t Kp, int64_t N) { return 2 * Kp * N; }
+// fp32 pack [Kp/4][N][4] | 16-bit hi / lo planes (Kp * N floats' worth) | trailer {1 / s, s, ...} (32 floats)
+extern "C" int64_t ofx_packed_floats(int64_t Kp, int64_t N) { return 2 * Kp * N + 32; }
 
 // aux[0, :] = 0; aux[1 + v, :] = mean over segment multi_seg[v] of x[col, :]
 __global__ void __launch_bounds__(256) multi_mean_kernel(const float* __restrict__ x, int64_t ldx, int cin,
@@ -952,6 +961,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmArgs g) {
     const int64_t m = t / g.N, n = t - m * g.N;
     float v = 0.f;
     for (int s = 0; s < g.nsplit; ++s) v += g.ws[(int64_t)s * total + t];
+    if (g.oscale_p) v *= *g.oscale_p;
     if (g.bias) v += g.bias[n];
     if (g.emb) v += g.emb[(int64_t)g.bid[m] * g.lde + n];
     if (g.res) v += g.res[m * g.ldr + n];
@@ -987,6 +997,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_v4_kernel(const GemmArgs g)
       f4add(v, a0); f4add(v, a1); f4add(v, a2); f4add(v, a3);
     }
     for (; s < g.nsplit; ++s) f4add(v, *reinterpret_cast<const float4*>(p + (int64_t)s * total));
+    if (g.oscale_p) { const float osc = *g.oscale_p; v.x *= osc; v.y *= osc; v.z *= osc; v.w *= osc; }
     if (g.bias) f4add(v, *reinterpret_cast<const float4*>(g.bias + n));
     if (g.emb) f4add(v, *reinterpret_cast<const float4*>(g.emb + (int64_t)g.bid[m] * g.lde + n));
     if (g.res) f4add(v, *reinterpret_cast<const float4*>(g.res + m * g.ldr + n));
@@ -1146,6 +1157,8 @@ static int launch_gemm(GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st) 
   if (!(g.stats && g.vec4 && nsplit == 1 && g.stats_part &&
         (size_t)nwr * g.N * 2 * sizeof(float) <= g.stats_part_bytes && (((uintptr_t)g.stats_part) & 15) == 0))
     g.stats_part = nullptr;
+  // the 16-bit halves carry the pack's power-of-two scale; the fp32 pack (exact kernels below) does not
+  g.oscale_p = (fast && g.W16) ? g.Wp + 2 * g.Kp * g.N : nullptr;
   if (fast && g.W16) {
     if (bn == 32) rc = launch_bf16x3_cfg<MODE, 4, 1, 1, 1>(g, st);
     else if (bn == 64) rc = launch_bf16x3_cfg<MODE, 2, 2, 2, 1>(g, st);

@@ -37,6 +37,8 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
   extern __shared__ __attribute__((aligned(128))) char smem2[];
   const GemmArgs& g = a.e;
 
+  float osc = *g.oscale_p;            // epilogue scale (ofx_planes.h), read here: no scalar load near the k-loop's waits
+  asm volatile("" : "+s"(osc));
   const int ntile = g.ntm * g.ntn;
   int bid = blockIdx.x;
   {   // XCD-aware bijective tile order: consecutive row tiles (Morton neighbours) share one XCD's L2
@@ -519,7 +521,7 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
 #undef G2_FENCE
   if (dbg) ts3 = g2_clock();
 
-  if (vec4) g2_epilogue_finish<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, P, m0, n0, wm, wn, l31, h);
+  if (vec4) g2_epilogue_finish<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, P, m0, n0, wm, wn, l31, h, osc);
   else epilogue_store_scalar<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, m0, n0, wm, wn, l31, h, 0);
   if (dbg) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -538,9 +540,11 @@ __global__ void __launch_bounds__(512, 2) gconv2_kernel(const Gemm2Args a) {   /
 // 4q..4q+3 of a 32-channel chunk (one coalesced 128-B line in, 64 B hi + 64 B lo out, safe in place);
 // mode 1: fp16 row-major (8 B per lane).
 __global__ void __launch_bounds__(256) planes_split_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int C,
-                                                           int Cpad, int mode, char* __restrict__ out, int64_t ldo) {
+                                                           int Cpad, int mode, char* __restrict__ out, int64_t ldo,
+                                                           uint32_t* __restrict__ range_words) {
   const int CT = Cpad >> 2;
   const int64_t total = n * CT;
+  unsigned sat = 0;             // operands beyond the fp16 range (modes 1 / 3: they become Inf / NaN): include/ofx.h, range guard
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = t / CT;
     const int c = (int)(t - r * CT) * 4;
@@ -552,6 +556,8 @@ __global__ void __launch_bounds__(256) planes_split_kernel(const float* __restri
       if (c + 1 < C) v.y = x[r * ldx + c + 1];
       if (c + 2 < C) v.z = x[r * ldx + c + 2];
     }
+    if (mode != 2)        // (!(a <= b) also catches NaN)
+      sat += !(fabsf(v.x) <= 65504.f) + !(fabsf(v.y) <= 65504.f) + !(fabsf(v.z) <= 65504.f) + !(fabsf(v.w) <= 65504.f);
     if (g2_pairs(mode)) {
       unsigned h0, h1, l0, l1;
       g2_split2(mode, v.x, v.y, h0, l0);
@@ -563,6 +569,7 @@ __global__ void __launch_bounds__(256) planes_split_kernel(const float* __restri
       *reinterpret_cast<uint2*>(out + r * ldo + c * 2) = make_uint2(g2_pk_f16(v.x, v.y), g2_pk_f16(v.z, v.w));
     }
   }
+  if (sat && range_words) atomicAdd(range_words, sat);
 }
 
 extern "C" int ofx_planes_split(const float* x, int64_t ldx, int64_t n, int C, int Cpad, int mode, void* out,
@@ -574,7 +581,8 @@ extern "C" int ofx_planes_split(const float* x, int64_t ldx, int64_t n, int C, i
   if (C >= 4 && ((ldx & 3) || ((uintptr_t)x & 15))) return OFX_EINVAL;
   if (n > 0)
     planes_split_kernel<<<ofx_grid(n * (Cpad / 4), 256), 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, Cpad, mode,
-                                                                                      (char*)out, ldo_bytes);
+                                                                                      (char*)out, ldo_bytes,
+                                                                                      ofx_range_words());
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
@@ -678,8 +686,11 @@ extern "C" int64_t ofx_planes_packed_ktiles(int cin, int nt, int mode) {
   const int64_t ch = g2_chunk(mode);
   return 7 * ((int64_t)cin / ch) + (nt > 1 ? (7 * (int64_t)nt + ch - 1) / ch : 0);
 }
+// + one 128-B trailer line: float [0] = 1 / s, [1] = s, the per-tensor power-of-two scale the 16-bit halves were
+// written with (include/ofx.h, range guard); the kernels' epilogue multiplies the accumulators by trailer[0]
+constexpr int64_t G2_TRAILER = 128;
 extern "C" int64_t ofx_planes_packed_bytes(int cin, int nt, int cout, int mode) {
-  return ofx_planes_packed_ktiles(cin, nt, mode) * (int64_t)cout * G2_LINE;
+  return ofx_planes_packed_ktiles(cin, nt, mode) * (int64_t)cout * G2_LINE + G2_TRAILER;
 }
 
 __global__ void __launch_bounds__(256) planes_pack_kernel(const float* __restrict__ W, int64_t sk, int64_t sn, int cin,
@@ -687,6 +698,7 @@ __global__ void __launch_bounds__(256) planes_pack_kernel(const float* __restric
                                                           char* __restrict__ out) {
   // one thread per 16-B piece: (k tile, column, piece)
   const int64_t total = nkt * N * 8;
+  const float wscale = reinterpret_cast<const float*>(out + nkt * N * G2_LINE)[1];     // written by weight_scale_kernel
   const int ch = g2_pairs(mode) ? 32 : 64;
   const int64_t Kf = 7 * (int64_t)cin;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -705,7 +717,7 @@ __global__ void __launch_bounds__(256) planes_pack_kernel(const float* __restric
         const int64_t kk = k - Kf, dir = kk / ntc, ty = kk - dir * ntc;
         src = dir * (cin + ntc) + cin + ty;
       }
-      w[e] = src >= 0 ? W[src * sk + n * sn] : 0.f;
+      w[e] = src >= 0 ? W[src * sk + n * sn] * wscale : 0.f;
     }
     u32x4 o;
     if (g2_pairs(mode)) {
@@ -729,7 +741,10 @@ extern "C" int ofx_pack_weights_planes(const float* W, int64_t sk, int64_t sn, i
       ((uintptr_t)out & 15))
     return OFX_EINVAL;
   const int64_t nkt = ofx_planes_packed_ktiles(cin, nt, mode);
-  planes_pack_kernel<<<ofx_grid(nkt * cout * 8, 256), 256, 0, ofx_stream(stream)>>>(W, sk, sn, cin, nt > 1 ? nt : 0,
+  const int ntc = nt > 1 ? nt : 0;
+  weight_scale_kernel<<<1, 1024, 0, ofx_stream(stream)>>>(W, sk, sn, 7 * (int64_t)(cin + ntc), cout, mode != 2 ? 1 : 0,
+                                                          reinterpret_cast<float*>((char*)out + nkt * cout * G2_LINE));
+  planes_pack_kernel<<<ofx_grid(nkt * cout * 8, 256), 256, 0, ofx_stream(stream)>>>(W, sk, sn, cin, ntc,
                                                                                     cout, nkt, mode, (char*)out);
   OFX_LAUNCH_CHECK();
   return OFX_OK;
@@ -847,6 +862,7 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
   GemmArgs& g = a.e;
   g.M = n_nodes; g.N = cout; g.K = g.Kp = (int64_t)a.nkt * ch; g.bias = bias; g.emb = emb; g.lde = lde; g.bid = batch_id;
   g.res = res; g.ldr = ldr; g.out = out; g.ldc = ldc; g.nsplit = 1;
+  g.oscale_p = reinterpret_cast<const float*>((const char*)W2 + (int64_t)a.nkt * cout * G2_LINE);    // the pack's trailer
   {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     g.vec4 = g.N % 4 == 0 && al16(g.out) && g.ldc % 4 == 0 && (!g.res || (al16(g.res) && g.ldr % 4 == 0)) &&

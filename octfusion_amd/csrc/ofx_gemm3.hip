@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
     asm volatile("" : "+s"(lo), "+s"(hi));
     return ((uint64_t)hi << 32) | lo;
   };
+  const float osc = __builtin_bit_cast(float, sgpr32(__builtin_bit_cast(int, *g.oscale_p)));   // (epilogue only)
   const char* const xlo = a.xp < a.aux ? a.xp : a.aux;
   const int64_t wstep = (int64_t)sgpr64((uint64_t)(g.N * (int64_t)G2_LINE));   // bytes per k tile of the packed weights
   const int tpd = sgpr32(a.tpd), nkt_g = sgpr32(a.nkt_g), nkt = sgpr32(a.nkt);
@@ -655,7 +656,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
       {
         const int tid = opaque_tid();
         const int w = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
-        g2_epilogue_finish<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, P, m0, n0, w >> 1, w & 1, ln & 31, ln >> 5, emb_line);   // (vec4 only: host-checked)
+        g2_epilogue_finish<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, P, m0, n0, w >> 1, w & 1, ln & 31, ln >> 5, osc, emb_line);   // (vec4 only: host-checked)
       }
     } else {
       // a middle / tail piece: publish the raw accumulators (lane-linear float4 slabs), write-through

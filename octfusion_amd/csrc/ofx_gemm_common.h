@@ -20,6 +20,8 @@ struct GemmArgs {
   int64_t M, K;            // K: logical K for dense bounds; gather uses Kp only
   const float* Wp; int64_t Kp, N;
   const uint16_t* W16;     // bf16 hi | lo split of the packed weights ([k/8][n][8] each), or NULL
+  const float* oscale_p;   // device float: the accumulators are multiplied by it before the epilogue terms (the inverse of
+                           // the power-of-two scale the 16-bit weight halves were packed with); NULL = 1
   const float* bias;
   const float* emb; int64_t lde; const int32_t* bid;
   const float* res; int64_t ldr;
@@ -34,6 +36,37 @@ struct GemmArgs {
   // at 75 us of a 300 us kernel).
   float* stats_part; size_t stats_part_bytes;
 };
+
+// scale[0] = 1/s, scale[1] = s with s = 2^e such that max|w| * s lies in [2^14, 2^15) (fp16 operands: modes 1 and 3;
+// bf16 pairs have fp32's exponent range: s = 1).  One block; pack time only.
+static __global__ void __launch_bounds__(1024) weight_scale_kernel(const float* __restrict__ W, int64_t sk, int64_t sn, int64_t K,
+                                                            int64_t N, int fp16_operands, float* __restrict__ scale) {
+  __shared__ float red[1024];
+  float m = 0.f;
+  for (int64_t t = threadIdx.x; t < K * N; t += 1024) {
+    const float a = fabsf(W[(t / N) * sk + (t % N) * sn]);
+    if (a <= 3.0e38f) m = fmaxf(m, a);                  // (Inf / NaN weights: left to the arithmetic, not to the scale)
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float s = 1.f;
+    if (fp16_operands && red[0] > 0.f) {
+      int e;
+      frexpf(red[0], &e);                               // red[0] = f * 2^e, f in [0.5, 1)
+      int sh = 15 - e;                                  // max|w| * 2^sh in [2^14, 2^15)
+      sh = sh < -60 ? -60 : (sh > 60 ? 60 : sh);
+      s = ldexpf(1.f, sh);
+    }
+    scale[0] = 1.f / s;
+    scale[1] = s;
+  }
+}
+
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void f4add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
@@ -61,6 +94,7 @@ __device__ __forceinline__ void epilogue_store_scalar(const GemmArgs& g, f32x16 
       continue;
     }
     const float bv = g.bias ? g.bias[n] : 0.f;
+    const float osc = g.oscale_p ? *g.oscale_p : 1.f;
     int sb = -1;                 // statistics run: batch id, sum, sum of squares
     float ssum = 0.f, ssq = 0.f;
 #pragma unroll
@@ -69,7 +103,7 @@ __device__ __forceinline__ void epilogue_store_scalar(const GemmArgs& g, f32x16 
       for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m >= g.M) continue;
-        float v = acc[i][j][r] + bv;
+        float v = fmaf(acc[i][j][r], osc, bv);
         int b = 0;
         if (g.emb || g.stats) b = g.bid[m];
         if (g.emb) v += g.emb[(int64_t)b * g.lde + n];
@@ -129,6 +163,7 @@ __device__ __forceinline__ void epilogue_store_v4(const GemmArgs& g, f32x16 (&ac
   const bool q0 = q & 1, q1 = q & 2;
   const int64_t mw = m0 + wm * MI * 32;                     // first row of this wave
   const int64_t blockIdx_tm = m0 / (WM * MI * 32);          // row-tile index of the block
+  const float osc = g.oscale_p ? *g.oscale_p : 1.f;
   // batch ids of this lane's rows; wave-uniform batch id -> statistics are reduced across the wave first
   int bids[MI][4];
   bool uni = true;
@@ -168,7 +203,7 @@ __device__ __forceinline__ void epilogue_store_v4(const GemmArgs& g, f32x16 (&ac
       for (int G = 0; G < 4; ++G) {                         // every lane takes part in the transposes
         float v0 = acc[i][j][4 * G], v1 = acc[i][j][4 * G + 1], v2 = acc[i][j][4 * G + 2], v3 = acc[i][j][4 * G + 3];
         quad_transpose(v0, v1, v2, v3, q0, q1);
-        t[G] = make_float4(v0 + bv.x, v1 + bv.y, v2 + bv.z, v3 + bv.w);
+        t[G] = make_float4(fmaf(v0, osc, bv.x), fmaf(v1, osc, bv.y), fmaf(v2, osc, bv.z), fmaf(v3, osc, bv.w));
       }
 #pragma unroll
       for (int G = 0; G < 4; ++G) {

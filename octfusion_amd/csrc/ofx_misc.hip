@@ -28,6 +28,20 @@ extern "C" int ofx_device_check(void) {
   return OFX_ENODEV;
 }
 
+static uint32_t* g_range_words[OFX_MAX_DEVICES] = {};
+extern "C" int ofx_set_range_words(uint32_t* words) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= OFX_MAX_DEVICES) return OFX_ENODEV;
+  if (words && ((uintptr_t)words & 3)) return OFX_EINVAL;
+  g_range_words[dev] = words;
+  return OFX_OK;
+}
+uint32_t* ofx_range_words() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= OFX_MAX_DEVICES) return nullptr;
+  return g_range_words[dev];
+}
+
 // dst[dmap(i), :] = src[smap(i), :]
 __global__ void __launch_bounds__(256) rows_copy_v4(const float* __restrict__ src, int64_t lds, const int32_t* __restrict__ smap,
                                                     float* __restrict__ dst, int64_t ldd, const int32_t* __restrict__ dmap,

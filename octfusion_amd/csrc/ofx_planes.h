@@ -17,8 +17,10 @@ typedef __attribute__((address_space(3))) void* ldsp;
 //   mode 2: bf16 pairs (8 + 8 significand bits: a = hi + lo to 2^-18 relative) -- "bf16x3";
 //   mode 3: fp16 pairs (11 + 11 bits: a = hi + lo to 2^-23 relative while lo is a normal fp16, to 2^-25 ABSOLUTE
 //           below -- v_mfma_f32_32x32x16_f16 honours fp16 denormal inputs on gfx950, tools/probes/mfma_f16_denorm.hip)
-//           -- "fp16x3": the same three MFMAs per product, ~30x less rounding than bf16x3.  Values are saturated to the
-//           fp16 range (+-65504) first: normalised activations and weights are many orders of magnitude below it.
+//           -- "fp16x3": the same three MFMAs per product, ~30x less rounding than bf16x3.  Values beyond the fp16
+//           range (+-65504) are NOT saturated: hi becomes +-Inf, lo = x - hi = -+Inf, and every product they enter is
+//           NaN -- the result is loudly non-finite and the caller retries in bf16x3 (include/ofx.h, range guard).
+//           Normalised activations are many orders of magnitude below the limit; weights are scaled per tensor.
 __device__ __forceinline__ unsigned g2_pk_bf16(float a, float b) {
   unsigned r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -36,7 +38,6 @@ __device__ __forceinline__ float g2_sat16(float v) { return fminf(fmaxf(v, -6550
 // (a, b) -> packed hi pair + packed lo pair
 __device__ __forceinline__ void g2_split2(int mode, float a, float b, unsigned& hi, unsigned& lo) {
   if (mode == 3) {
-    a = g2_sat16(a); b = g2_sat16(b);
     hi = g2_pk_f16(a, b);
     lo = g2_pk_f16(a - g2_f16_lo(hi), b - g2_f16_hi(hi));
   } else {
@@ -306,11 +307,14 @@ __device__ __forceinline__ void g2_epilogue_landed(G2Epi<2, 1>& P) {
 
 template <int WM, int WN, int MI, int NI>
 __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&acc)[MI][NI], G2Epi<MI, NI>& P, int64_t m0,
-                                                   int64_t n0, int wm, int wn, int l31, int h, bool emb_in_bias = false) {
+                                                   int64_t n0, int wm, int wn, int l31, int h, float osc,
+                                                   bool emb_in_bias = false) {
   const int q = l31 & 3, k = l31 >> 2;
   const bool q0 = q & 1, q1 = q & 2;
   const int64_t mw = m0 + wm * MI * 32;
   const int64_t tile_m = m0 / (WM * MI * 32);
+  // osc: inverse of the power-of-two scale the weight halves were packed with (ofx.h, range guard), read once at
+  // kernel entry into an SGPR: folded into the FMA that adds the bias, so it costs no instruction.
   bool uni = true;
   int b0 = 0;
   // A wave whose 64 rows lie in TWO batch elements (the tile holds a batch boundary: ~20 tiles per launch, but with
@@ -393,7 +397,7 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
         for (int G = 0; G < 4; ++G) {                         // every lane takes part in the transposes
           float v0 = acc[i][j][4 * G], v1 = acc[i][j][4 * G + 1], v2 = acc[i][j][4 * G + 2], v3 = acc[i][j][4 * G + 3];
           quad_transpose(v0, v1, v2, v3, q0, q1);
-          t[G] = make_float4(v0 + bv.x, v1 + bv.y, v2 + bv.z, v3 + bv.w);
+          t[G] = make_float4(fmaf(v0, osc, bv.x), fmaf(v1, osc, bv.y), fmaf(v2, osc, bv.z), fmaf(v3, osc, bv.w));
         }
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
@@ -455,7 +459,7 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
         for (int G = 0; G < 4; ++G) {
           float v0 = acc[i][j][4 * G], v1 = acc[i][j][4 * G + 1], v2 = acc[i][j][4 * G + 2], v3 = acc[i][j][4 * G + 3];
           quad_transpose(v0, v1, v2, v3, q0, q1);
-          t[G] = make_float4(v0 + bv.x, v1 + bv.y, v2 + bv.z, v3 + bv.w);
+          t[G] = make_float4(fmaf(v0, osc, bv.x), fmaf(v1, osc, bv.y), fmaf(v2, osc, bv.z), fmaf(v3, osc, bv.w));
         }
 #pragma unroll
         for (int G = 0; G < 4; ++G) {

@@ -155,6 +155,7 @@ def planes_split(x, mode, Cpad=None, out=None):
     ch = _planes_chunk(mode)
     Cpad = Cpad if Cpad is not None else (C + ch - 1) // ch * ch
     out, ldo = _planes_out(n, Cpad, mode, x.device, out)
+    range_words(x.device)
     _meta('planes_split', 0, 4.0 * n * C + (4.0 if planes_pairs(mode) else 2.0) * n * Cpad, (n, C, Cpad))
     call('ofx_planes_split', ptr(x), ldx, n, C, Cpad, mode, ptr(out), ldo, stream())
     setattr(out, PLANES_ATTR, mode)
@@ -310,6 +311,57 @@ def raise_on_sync_error(device):
     call('ofx_set_gconv_persistent', 0)
     raise _lib.OfxError('a flag wait of the persistent GraphConv launch gave up on %s: the results of this call are '
                         'invalid; the process now uses the one-tile-per-block launch (ofx_set_gconv_persistent(0))' % device)
+
+
+_RANGE = {}
+AUTO_RANGE_FALLBACK = True     # raise_on_range_error switches the process to 'bf16x3' before raising (the retry then fits)
+
+
+class OfxRangeError(_lib.OfxError):
+    """An operand left the range the fp16-pair contraction covers (include/ofx.h, fp16x3 range guard)."""
+
+
+def range_words(device):
+    """The device's sticky fp16x3 range-guard words (include/ofx.h), registered with the library on first use:
+    [0] = operands ofx_planes_split found outside the fp16 range (|x| > 65504 or non-finite)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _RANGE.get(key)
+    if t is None:
+        with torch.cuda.device(key[1]):
+            t = _RANGE[key] = torch.zeros(4, dtype=torch.int32, device=device)
+            call('ofx_set_range_words', ptr(t))
+    return t
+
+
+def range_error(device, result=None):
+    """{'operands_beyond_fp16': n, 'result_non_finite': bool} if operands left the fp16 range on `device` since the words
+    were last cleared -- or `result` (a tensor the suspect launches produced) is non-finite: an operand beyond the range
+    poisons everything downstream with NaN -- else None (host sync)."""
+    t = _RANGE.get((device.type, device.index if device.index is not None else torch.cuda.current_device()))
+    n = int(t[0].item()) if t is not None else 0
+    bad = result is not None and not bool(torch.isfinite(result).all())
+    return {'operands_beyond_fp16': n, 'result_non_finite': bad} if (n or bad) else None
+
+
+def raise_on_range_error(device, result=None):
+    """Production check, once per sampling stage next to raise_on_sync_error.  With the fp16-pair contraction active,
+    operands beyond +-65504 turn the result into NaN (they are not clamped): a non-finite `result`, or a non-zero
+    out-of-range count, means this call's results are invalid.  Clears the words and raises OfxRangeError; with
+    AUTO_RANGE_FALLBACK the process is switched to 'bf16x3' (fp32's exponent range, 16 significand bits) first, so
+    that the caller's retry (pipeline.CascadeSampler.sample retries once by itself) succeeds.  In any other precision
+    a non-finite result is the model's own (diverged weights / inputs): OfxError."""
+    err = range_error(device, result)
+    if err is None:
+        return
+    range_words(device).zero_()
+    was = get_precision()
+    if was not in ('fp16x3', 'fp16'):
+        raise _lib.OfxError('non-finite result on %s in precision %s (%s)' % (device, was, err))
+    if AUTO_RANGE_FALLBACK and was == 'fp16x3':
+        set_precision('bf16x3')
+    raise OfxRangeError('fp16x3 range guard on %s: %s -- operands beyond +-65504 do not fit the fp16 operand pairs; the '
+                        'results of this call are invalid%s' % (device, err, '; the process now computes in bf16x3: call again'
+                                                               if AUTO_RANGE_FALLBACK and was == 'fp16x3' else ''))
 
 
 def workspace(device, nbytes=96 << 20):
@@ -676,6 +728,7 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
     x, ldx = _row_major(x)
     n, C = x.shape
     dev = x.device
+    range_words(dev)
     if rows_per_batch is not None and stats is None and not planes and rows_per_batch * (C // groups) <= (1 << 16):
         assert n == rows_per_batch * batch_size
         if out is None:

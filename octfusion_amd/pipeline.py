@@ -107,8 +107,22 @@ class CascadeSampler:
         return init, steps
 
     @torch.no_grad()
-    def sample(self, batch_size, ddim_steps=200, label=None, split_small=None, noises=None, sdf_resolution=None,
-               sdf_scale=0.9, use_graph=None, seed=None, save_index=0, shape_indices=None, timings=None):
+    def sample(self, *args, **kwargs):
+        """_sample_once, retried ONCE when the fp16x3 range guard trips (ops.raise_on_range_error: operands beyond the
+        fp16 range; the process has been switched to bf16x3 by then).  With per-shape generators or a seed the retry
+        draws the same noise; a caller that relies on the global RNG state gets a fresh draw."""
+        from . import ops
+        try:
+            return self._sample_once(*args, **kwargs)
+        except ops.OfxRangeError:
+            if ops.get_precision() == 'fp16x3':
+                raise
+            import warnings
+            warnings.warn('octfusion_amd: fp16x3 range guard tripped -- sampling again in bf16x3')
+            return self._sample_once(*args, **kwargs)
+
+    def _sample_once(self, batch_size, ddim_steps=200, label=None, split_small=None, noises=None, sdf_resolution=None,
+                     sdf_scale=0.9, use_graph=None, seed=None, save_index=0, shape_indices=None, timings=None):
         """Returns a dict with the per-stage results.  `noises` (optional) = dict of explicit
         init / step noise tensors per stage for reproducible runs.  sdf_resolution (e.g. 256) adds
         out['sdfs'] [B, R, R, R] (needs the VAE).

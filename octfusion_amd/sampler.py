@@ -143,4 +143,5 @@ def sample_loop(net, shape, batch_size, ddim_steps, unet_type, df_type, device, 
         x_start = res
     if x.is_cuda:
         ops.raise_on_sync_error(x.device)       # (one host read per stage; the caller synchronises right after anyway)
+        ops.raise_on_range_error(x.device, x)
     return x

@@ -309,18 +309,33 @@ def _dgn_bwd(norm, x, dy, doctree, d, act, G, prefix):
     return dx
 
 
-def _gres_fwd(blk, x, emb_act, doctree, d):
+# Activation checkpointing (ldm_diffusion_util.py:158-169; GraphResBlockEmbed.forward wraps _forward in
+# checkpoint(..., self.use_checkpoint), modules.py:730-743; the Objaverse config sets use_checkpoint: True): a block
+# built with use_checkpoint keeps only its INPUT for the backward and recomputes GroupNorm -> conv1 -> GroupNorm there
+# (three of the four tensors the plain path keeps per block; at N8 = 3.25 M rows x 64..256 channels that is the
+# difference between fitting a batch and not).  CHECKPOINT: None = follow the module's flag, True / False = force (A/B).
+CHECKPOINT = None
+
+
+def _gres_recompute(blk, x, emb_act, doctree, d):
     h1 = blk.block1_norm(x, doctree, d, act='silu')
-    emb_out = blk.emb_layers[1](emb_act)
-    c1 = blk.conv1(h1, doctree, d, emb=emb_out)
+    c1 = blk.conv1(h1, doctree, d, emb=blk.emb_layers[1](emb_act))
     h2 = blk.block2_norm(c1, doctree, d, act='silu')
+    return h1, c1, h2
+
+
+def _gres_fwd(blk, x, emb_act, doctree, d):
+    h1, c1, h2 = _gres_recompute(blk, x, emb_act, doctree, d)
     skip = x if isinstance(blk.skip_connection, nn.Identity) else blk.skip_connection(x)
     y = blk.conv2(h2, doctree, d, res=skip)
-    return y, (x, h1, c1, h2)
+    ckpt = blk.use_checkpoint if CHECKPOINT is None else CHECKPOINT
+    return y, ((x, None, None, None) if ckpt else (x, h1, c1, h2))
 
 
 def _gres_bwd(blk, saved, emb_act, dy, doctree, d, G, prefix):
     x, h1, c1, h2 = saved
+    if h1 is None:                       # checkpointed block: its intermediates are recomputed from the input
+        h1, c1, h2 = _gres_recompute(blk, x, emb_act, doctree, d)
     dh2 = _gconv_bwd(blk.conv2, h2, dy, doctree, d, G, prefix + 'conv2.')
     dc1 = _dgn_bwd(blk.block2_norm, c1, dh2, doctree, d, 'silu', G, prefix + 'block2_norm.')
     demb_out = batch_sums(dc1, doctree.batch_id32(d), doctree.batch_size)

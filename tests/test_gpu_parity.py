@@ -591,6 +591,48 @@ def test_hr_unet_backward_vs_autograd(golden):
         assert err <= 5e-3 * float(ref.abs().max()) + 2e-5 * gmax, (k, err, float(ref.abs().max()), gmax)
 
 
+def test_activation_checkpointing_gives_the_same_gradients(golden):
+    """ldm_diffusion_util.py:158-169 / modules.py:730-743 (use_checkpoint): a checkpointed res block keeps only its
+    input and recomputes GroupNorm -> conv1 -> GroupNorm in the backward -- same kernels on the same inputs, so the
+    output, the input gradient and every parameter gradient are BIT-identical to the plain path; and the module's own
+    flag (the constructor argument of the reference) is what switches it."""
+    from octfusion_amd import graph_unet_union as U, backward as BW
+    G = golden('g_unet')
+    r = G['uncond']
+    oc, doc = small(G['split_small'])
+    net = load(U.UNet3DModel(**union_cfg(None)), r['keys'])
+    N = doc.total_num
+    x = C.rand_input('hrb_x', N, 3)
+    dy = C.rand_input('hrb_dy', N, 3)
+    t = torch.tensor([0.4, -0.9])
+
+    def run():
+        return BW.hr_unet_forward_backward(net.unet_hr, x.to(dev()), doc, net.unet_lr, t.to(dev()), lambda out: dy.to(dev()))
+    kept = []
+    orig = BW._gres_fwd
+
+    def spy(*a, **k):
+        y, saved = orig(*a, **k)
+        kept.append(sum(v is not None for v in saved))
+        return y, saved
+    BW._gres_fwd = spy
+    try:
+        y0, dx0, g0, gl0 = run()
+        assert set(kept) == {4}
+        del kept[:]
+        blocks = [m for m in net.unet_hr.modules() if hasattr(m, 'use_checkpoint') and hasattr(m, 'block1_norm')]
+        assert blocks and not any(b.use_checkpoint for b in blocks)
+        for b in blocks:
+            b.use_checkpoint = True                      # what UNet3DModel(use_checkpoint=True) sets (graph_unet_hr.py:66)
+        y1, dx1, g1, gl1 = run()
+        assert set(kept) == {1}                          # only the block input is kept
+    finally:
+        BW._gres_fwd = orig
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    assert set(g0) == set(g1) and all(torch.equal(g0[k], g1[k]) for k in g0)
+    assert all(torch.equal(gl0[k], gl1[k]) for k in gl0)
+
+
 def test_feature_unet_backward_vs_autograd(golden):
     """3-stage cascade: the feature net with the hr net nested as its middle (itself running as_middle, without an
     lr net) -- forward + backward against autograd through the oracle, all parameters that take part."""

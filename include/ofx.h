@@ -339,6 +339,12 @@ int ofx_gemm_f32(const float* A, int64_t lda, const int32_t* a_rows, int64_t M, 
                  const float* Wp, int64_t Kp, int64_t N, const float* bias,
                  const float* res, int64_t ldr, float* out, int64_t ldc,
                  const int32_t* out_rows, void* ws, size_t ws_bytes, void* stream);
+/* The same GEMM writing `out` as hi / lo pair planes (out_mode 2 = bf16 pairs, 3 = fp16 pairs; 0 = fp32 rows, i.e.
+ * ofx_gemm_f32): needs N % 4 == 0, a 128-B aligned `out` with ldc % 32 == 0 and 16-B aligned res / bias / ws. */
+int ofx_gemm_f32_planes(const float* A, int64_t lda, const int32_t* a_rows, int64_t M, int64_t K,
+                        const float* Wp, int64_t Kp, int64_t N, const float* bias,
+                        const float* res, int64_t ldr, float* out, int64_t ldc,
+                        const int32_t* out_rows, void* ws, size_t ws_bytes, int out_mode, void* stream);
 
 /* ---------------------------------------------------------------- GraphConv
  * Fused dual-octree graph convolution (modules.py:194-220 + scatter.py:42-66):
@@ -519,11 +525,23 @@ int ofx_set_gn_rows16(int on);
 /* dst[dmap(i), 0:C] = src[smap(i), 0:C] for i < n (maps optional; negative skips). */
 int ofx_rows_copy(const float* src, int64_t lds, const int32_t* smap, float* dst, int64_t ldd,
                   const int32_t* dmap, int64_t n, int C, void* stream);
+/* ofx_rows_copy writing the destination rows as hi / lo pair planes (mode 2 / 3: the operand format of
+ * ofx_graphconv_fwd_planes): C % 32 == 0, dst 128-B aligned, ldd % 32 == 0.  With ofx_gemm_f32_planes this lets the
+ * pool / unpool of the U-Net (modules.py:409-423, 458-467) hand the following GraphConv its operand planes directly. */
+int ofx_rows_copy_planes(const float* src, int64_t lds, const int32_t* smap, float* dst, int64_t ldd,
+                         const int32_t* dmap, int64_t n, int C, int mode, void* stream);
 /* y = act(x) elementwise over n floats. */
 int ofx_act(const float* x, float* y, int64_t n, int act, void* stream);
 /* sinusoidal embedding of t[B] (ldm_diffusion_util.py:171-191): out [B, dim]. */
 int ofx_timestep_embedding(const float* t, int batch_size, int dim, float max_period,
                            float* out, void* stream);
+/* LearnedSinusoidalPosEmb of the dense net (modules.py:550-563): out [B, 2 * half + 1] = [t, sin(2 pi t w), cos(2 pi t w)]. */
+int ofx_learned_sinusoid(const float* t, const float* w, int batch_size, int half, float* out, void* stream);
+/* Linear layer on M <= 16 rows (time / label embedding MLPs, per-block embedding projections; modules.py:754,
+ * graph_unet_hr.py:253-257, graph_unet_lr.py:186-193): out = act_out(act_in(a) @ W^T + bias + res) with W [N, K] in
+ * nn.Linear's own layout (no packing), exact fp32 FMA, one launch.  act_* = OFX_ACT_*; bias / res optional. */
+int ofx_linear_small(const float* a, int64_t lda, int M, int K, const float* W, int64_t ldw, int N, const float* bias,
+                     const float* res, int64_t ldr, int act_in, int act_out, float* out, int64_t ldo, void* stream);
 /* DDIM eps-branch update (octfusion_model_union.py:345-350), coef on device:
  * coef = {alpha, sigma, alpha_next, sigma_next}; x updated in place; x0_out (optional)
  * receives x_start = (x - eps*sigma)/max(alpha,1e-8), which the reference hands to the next

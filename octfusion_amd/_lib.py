@@ -96,6 +96,7 @@ _SIGS = {
     'ofx_graphconv_packed_k': (c_l, [c_i, c_i], False),
     'ofx_pack_weights': (c_i, [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_p, c_l, c_p], True),
     'ofx_gemm_f32': (c_i, [c_p, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_sz, c_p], True),
+    'ofx_gemm_f32_planes': (c_i, [c_p, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_sz, c_i, c_p], True),
     'ofx_graphconv_fwd': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l,
                                 c_i, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_sz, c_p], True),
     'ofx_planes_split': (c_i, [c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_l, c_p], True),
@@ -129,8 +130,11 @@ _SIGS = {
     'ofx_gn_finalize': (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p], True),
     'ofx_gn_apply': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_i, c_p, c_l, c_p], True),
     'ofx_rows_copy': (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_p], True),
+    'ofx_rows_copy_planes': (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_p], True),
     'ofx_act': (c_i, [c_p, c_p, c_l, c_i, c_p], True),
     'ofx_timestep_embedding': (c_i, [c_p, c_i, c_i, c_f, c_p, c_p], True),
+    'ofx_learned_sinusoid': (c_i, [c_p, c_p, c_i, c_i, c_p, c_p], True),
+    'ofx_linear_small': (c_i, [c_p, c_l, c_i, c_i, c_p, c_l, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_l, c_p], True),
     'ofx_ddim_eps_update': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p], True),
     'ofx_ddim_x0_update': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p], True),
 }

@@ -1003,7 +1003,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_v4_kernel(const GemmArgs g)
     if (g.res) f4add(v, *reinterpret_cast<const float4*>(g.res + m * g.ldr + n));
     int64_t om = m;
     if (g.out_rows) { om = g.out_rows[m]; if (om < 0) continue; }
-    *reinterpret_cast<float4*>(g.out + om * g.ldc + n) = v;
+    if (g.out_planes) ofx_store_planes4(g.out, om * g.ldc + n, v, g.out_planes);
+    else *reinterpret_cast<float4*>(g.out + om * g.ldc + n) = v;
   }
 }
 
@@ -1267,18 +1268,29 @@ extern "C" int ofx_pack_conv3d(const float* W, int cin, int cout, float* Wp, voi
   return OFX_OK;
 }
 
-extern "C" int ofx_gemm_f32(const float* A, int64_t lda, const int32_t* a_rows, int64_t M, int64_t K, const float* Wp,
-                            int64_t Kp, int64_t N, const float* bias, const float* res, int64_t ldr, float* out,
-                            int64_t ldc, const int32_t* out_rows, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int ofx_gemm_f32_planes(const float* A, int64_t lda, const int32_t* a_rows, int64_t M, int64_t K,
+                                   const float* Wp, int64_t Kp, int64_t N, const float* bias, const float* res, int64_t ldr,
+                                   float* out, int64_t ldc, const int32_t* out_rows, void* ws, size_t ws_bytes,
+                                   int out_mode, void* stream) {
   if (M == 0 && K >= 1 && N >= 1) return OFX_OK;          // empty input: nothing to do (out may be a null pointer)
   if (M < 0 || K < 1 || N < 1 || !Wp || !out || (M > 0 && !A) || Kp != pad32(K) || lda < K || ldc < N ||
       (res && ldr < N) || ((uintptr_t)Wp & 15))
     return OFX_EINVAL;
+  if (out_mode != 0 && out_mode != 2 && out_mode != 3) return OFX_EINVAL;
+  // pair planes: the float4 epilogues only, whole 128-B lines (the planes of a buffer are a function of the flat index)
+  if (out_mode && ((N & 3) || (ldc & 31) || ((uintptr_t)out & 127) || (res && ((ldr & 3) || ((uintptr_t)res & 15))) ||
+                   (bias && ((uintptr_t)bias & 15)) || ((uintptr_t)ws & 15)))
+    return OFX_EINVAL;
   GemmArgs g = {};
   g.A = A; g.lda = lda; g.a_rows = a_rows;
   g.M = M; g.K = K; g.Wp = Wp; g.Kp = Kp; g.N = N; g.bias = bias;
-  g.res = res; g.ldr = ldr; g.out = out; g.ldc = ldc; g.out_rows = out_rows;
+  g.res = res; g.ldr = ldr; g.out = out; g.ldc = ldc; g.out_rows = out_rows; g.out_planes = out_mode;
   return launch_gemm<MODE_DENSE>(g, (float*)ws, ws_bytes, ofx_stream(stream));
+}
+extern "C" int ofx_gemm_f32(const float* A, int64_t lda, const int32_t* a_rows, int64_t M, int64_t K, const float* Wp,
+                            int64_t Kp, int64_t N, const float* bias, const float* res, int64_t ldr, float* out,
+                            int64_t ldc, const int32_t* out_rows, void* ws, size_t ws_bytes, void* stream) {
+  return ofx_gemm_f32_planes(A, lda, a_rows, M, K, Wp, Kp, N, bias, res, ldr, out, ldc, out_rows, ws, ws_bytes, 0, stream);
 }
 
 static int gather_common(GemmArgs& g, const float* x, int64_t ldx, int cin, int ndir, int64_t n_rows,

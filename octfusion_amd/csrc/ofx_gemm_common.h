@@ -26,6 +26,8 @@ struct GemmArgs {
   const float* emb; int64_t lde; const int32_t* bid;
   const float* res; int64_t ldr;
   float* out; int64_t ldc; const int32_t* out_rows;
+  int out_planes;          // 0: fp32 rows; 2 / 3: write `out` as bf16 / fp16 hi + lo pair planes (vec4 epilogues only; needs
+                           // a 128-B aligned `out` and ldc % 32 == 0): the consumer is the planes GraphConv
   double* stats; int64_t stats_ld;   // optional fused GroupNorm statistics: stats[(b*stats_ld + n)*2 + {0,1}] += (v, v*v)
   int ntm, ntn, nsplit, kt_per_split;
   float* ws;               // split-K partials [nsplit][M][N]
@@ -67,6 +69,49 @@ static __global__ void __launch_bounds__(1024) weight_scale_kernel(const float* 
   }
 }
 
+
+// ---- 16-bit operand pairs (formats: ofx_planes.h)
+__device__ __forceinline__ unsigned g2_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned g2_pk_f16(float a, float b) {
+  const _Float16 x = (_Float16)a, y = (_Float16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ float g2_bf16_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float g2_bf16_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+__device__ __forceinline__ float g2_f16_lo(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
+__device__ __forceinline__ float g2_f16_hi(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
+__device__ __forceinline__ float g2_sat16(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
+// (a, b) -> packed hi pair + packed lo pair
+__device__ __forceinline__ void g2_split2(int mode, float a, float b, unsigned& hi, unsigned& lo) {
+  if (mode == 3) {
+    hi = g2_pk_f16(a, b);
+    lo = g2_pk_f16(a - g2_f16_lo(hi), b - g2_f16_hi(hi));
+  } else {
+    hi = g2_pk_bf16(a, b);
+    lo = g2_pk_bf16(a - g2_bf16_lo(hi), b - g2_bf16_hi(hi));
+  }
+}
+__device__ __forceinline__ void g2_join2(int mode, unsigned hi, unsigned lo, float& a, float& b) {
+  if (mode == 3) { a = g2_f16_lo(hi) + g2_f16_lo(lo); b = g2_f16_hi(hi) + g2_f16_hi(lo); }
+  else { a = g2_bf16_lo(hi) + g2_bf16_lo(lo); b = g2_bf16_hi(hi) + g2_bf16_hi(lo); }
+}
+__host__ __device__ static inline bool g2_pairs(int mode) { return mode == 2 || mode == 3; }   // [hi x 32 | lo x 32] lines
+
+// Store four consecutive floats as their hi / lo pair planes.  `f` = flat float index (a multiple of 4) into a 128-B
+// aligned buffer whose row pitch is a multiple of 32 floats: a 32-float group is one 128-B line [hi x 32 | lo x 32]
+// whatever the row structure, so the planes of an fp32-shaped buffer are a function of the flat index alone.
+__device__ __forceinline__ void ofx_store_planes4(float* base, int64_t f, const float4& v, int mode) {
+  unsigned h0, h1, l0, l1;
+  g2_split2(mode, v.x, v.y, h0, l0);
+  g2_split2(mode, v.z, v.w, h1, l1);
+  char* o = reinterpret_cast<char*>(base) + (f >> 5) * 128 + (f & 31) * 2;
+  *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(o + 64) = make_uint2(l0, l1);
+}
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void f4add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
@@ -224,7 +269,8 @@ __device__ __forceinline__ void epilogue_store_v4(const GemmArgs& g, f32x16 (&ac
         }
         int64_t om = m;
         if (g.out_rows) { om = g.out_rows[m]; if (om < 0) continue; }
-        *reinterpret_cast<float4*>(g.out + om * g.ldc + n) = v;
+        if (g.out_planes) ofx_store_planes4(g.out, om * g.ldc + n, v, g.out_planes);
+        else *reinterpret_cast<float4*>(g.out + om * g.ldc + n) = v;
       }
     }
     if (g.stats) {

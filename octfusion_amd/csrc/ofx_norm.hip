@@ -20,10 +20,17 @@ constexpr int GN_ROWS_PER_BLOCK = 64;
 // (measured: 780 k rows x 32 channels, batch 4, 64-row blocks -> 3 k atomics per address, 318 us = 0.3 TB/s; 64 k rows
 // -> 253 per address, 69 us for 8 MB).  Blocks are therefore capped at 128 per batch element (at least 256: enough
 // to stream) and own proportionally more consecutive rows.
-static inline int64_t gn_stats_rows(int64_t n, int batch_size) {
+// Small tensors (the 16 MB concat in the middle of the hr net: 32 768 rows x 128, batch 8) are the other end of the
+// same trade: 64-row blocks put 64 atomics on every address -- 13 us of serialised atomics for 3 us of reading
+// (28 us per call in the round-4 step trace) -- so a block also owns at least ~128 KB of rows (>= 8 blocks per batch
+// element are kept so that the read still spreads over the chip).
+static inline int64_t gn_stats_rows(int64_t n, int batch_size, int C = 128) {
   const int64_t chunks = (n + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK;
-  int64_t cap = 128 * (int64_t)batch_size;
-  if (cap < 256) cap = 256;
+  const int64_t bytes_per_batch = n * (int64_t)C * 4 / (batch_size > 0 ? batch_size : 1);
+  int64_t per_batch = bytes_per_batch / (128 << 10);
+  per_batch = per_batch < 8 ? 8 : (per_batch > 128 ? 128 : per_batch);
+  int64_t cap = per_batch * (int64_t)batch_size;
+  if (cap < 64) cap = 64;
   return chunks <= cap ? GN_ROWS_PER_BLOCK : GN_ROWS_PER_BLOCK * ((chunks + cap - 1) / cap);
 }
 
@@ -105,8 +112,8 @@ extern "C" int ofx_gn_stats(const float* x, int64_t ldx, int64_t n, int C, const
     return OFX_EINVAL;
   hipStream_t st = ofx_stream(stream);
   if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)batch_size * C, st) != hipSuccess) return OFX_ELAUNCH;
-  if (n > 0) gn_stats_kernel<<<(int)ofx_cdiv(n, gn_stats_rows(n, batch_size)), 256, 0, st>>>(x, ldx, n, C, batch_id, sums,
-                                                                                          gn_stats_rows(n, batch_size));
+  if (n > 0) gn_stats_kernel<<<(int)ofx_cdiv(n, gn_stats_rows(n, batch_size, C)), 256, 0, st>>>(x, ldx, n, C, batch_id, sums,
+                                                                                             gn_stats_rows(n, batch_size, C));
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
@@ -214,13 +221,22 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
     pv2 = *reinterpret_cast<const float4*>(x + (r + 2 * RP) * ldx + c_);
     pv3 = *reinterpret_cast<const float4*>(x + (r + 3 * RP) * ldx + c_);
   }
-  if (FIN && !is_aux) {
-    const int64_t r_begin = r_begin0;
-    const int64_t r_last = r_end0 - 1;
-    fb0 = bid[r_begin];
-    fb1 = bid[r_last];
+  if (FIN) {
+    if (!is_aux) {
+      fb0 = bid[r_begin0];
+      fb1 = bid[r_end0 - 1];
+    } else {
+      // aux rows are ordered by segment = row * 7 + direction, i.e. by row, i.e. by batch element, and every source of
+      // a segment lies in the batch element of its row: the block's aux rows span the batch elements of its first and
+      // last segment's rows (two dependent loads; the zero row v = 0 needs no statistics)
+      const int64_t v0 = (int64_t)blockIdx.x * RP, v1e = v0 + RP - 1 < n_multi ? v0 + RP - 1 : n_multi;
+      if (n_multi > 0) {
+        fb0 = bid[multi_seg[(v0 > 0 ? v0 : 1) - 1] / 7];
+        fb1 = bid[multi_seg[(v1e > 0 ? v1e : 1) - 1] / 7];
+      }
+    }
     const int cpg = C / fin.G;
-    for (int t = threadIdx.x; t < 2 * fin.G; t += 256) {
+    for (int t = threadIdx.x; t < 2 * fin.G && fb0 >= 0; t += 256) {
       const int slot = t / fin.G, g = t - slot * fin.G;
       if (slot == 1 && fb1 == fb0) continue;
       float mm, rr;

@@ -21,35 +21,7 @@ typedef __attribute__((address_space(3))) void* ldsp;
 //           range (+-65504) are NOT saturated: hi becomes +-Inf, lo = x - hi = -+Inf, and every product they enter is
 //           NaN -- the result is loudly non-finite and the caller retries in bf16x3 (include/ofx.h, range guard).
 //           Normalised activations are many orders of magnitude below the limit; weights are scaled per tensor.
-__device__ __forceinline__ unsigned g2_pk_bf16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ unsigned g2_pk_f16(float a, float b) {
-  const _Float16 x = (_Float16)a, y = (_Float16)b;
-  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
-}
-__device__ __forceinline__ float g2_bf16_lo(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float g2_bf16_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
-__device__ __forceinline__ float g2_f16_lo(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
-__device__ __forceinline__ float g2_f16_hi(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
-__device__ __forceinline__ float g2_sat16(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
-// (a, b) -> packed hi pair + packed lo pair
-__device__ __forceinline__ void g2_split2(int mode, float a, float b, unsigned& hi, unsigned& lo) {
-  if (mode == 3) {
-    hi = g2_pk_f16(a, b);
-    lo = g2_pk_f16(a - g2_f16_lo(hi), b - g2_f16_hi(hi));
-  } else {
-    hi = g2_pk_bf16(a, b);
-    lo = g2_pk_bf16(a - g2_bf16_lo(hi), b - g2_bf16_hi(hi));
-  }
-}
-__device__ __forceinline__ void g2_join2(int mode, unsigned hi, unsigned lo, float& a, float& b) {
-  if (mode == 3) { a = g2_f16_lo(hi) + g2_f16_lo(lo); b = g2_f16_hi(hi) + g2_f16_hi(lo); }
-  else { a = g2_bf16_lo(hi) + g2_bf16_lo(lo); b = g2_bf16_hi(hi) + g2_bf16_hi(lo); }
-}
-__host__ __device__ static inline bool g2_pairs(int mode) { return mode == 2 || mode == 3; }   // [hi x 32 | lo x 32] lines
+// (g2_pk_* / g2_split2 / g2_join2 / g2_pairs live in ofx_gemm_common.h: the GEMM epilogues write planes too)
 
 // Two block geometries (template parameter WM = wave rows):
 //   WM = 4: 256 x 128 tile, 8 waves, 3 stage buffers (DMA two k-steps ahead), 152 KB LDS -> ONE block per CU;

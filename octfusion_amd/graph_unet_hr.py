@@ -126,7 +126,10 @@ class UNet3DModel(nn.Module):
             self._emb_cat_b = torch.cat([l.bias.detach() for l in lins], dim=0).contiguous()
             self._emb_cat_pw = ops.PackedWeight()
             self._emb_cat_key = key
-        allout = ops.gemm(emb_act, self._emb_cat_pw.get(self._emb_cat_w, 'nk'), self._emb_cat_b)
+        if ops.LINEAR_SMALL and emb_act.shape[0] <= 16:
+            allout = ops.linear_small(emb_act, self._emb_cat_w, self._emb_cat_b)
+        else:
+            allout = ops.gemm(emb_act, self._emb_cat_pw.get(self._emb_cat_w, 'nk'), self._emb_cat_b)
         outs, off = {}, 0
         for b, l in zip(blocks, lins):
             outs[id(b)] = allout[:, off:off + l.out_features]
@@ -147,12 +150,14 @@ class UNet3DModel(nn.Module):
         assert (label is not None) == (self.num_classes is not None), \
             'must specify y if and only if the model is class-conditional'
         t_emb = ops.timestep_embedding(timesteps.float(), self.model_channels)
-        emb = self.time_embed[0](t_emb)
-        emb = self.time_embed[2](ops.act(emb, 'silu'))
+        # time_embed = Linear -> SiLU -> Linear (+ label embedding), then every res-block applies SiLU to it
+        # (modules.py:754): the activations ride in the few-row linear launches
+        lab = None
         if self.num_classes is not None:
             assert label.shape == (doctree.batch_size,)
-            emb = emb + self.label_emb(label)
-        emb_act = ops.act(emb, 'silu')          # SiLU(emb) is what every res-block consumes
+            lab = self.label_emb(label)
+        emb_act = self.time_embed[2](self.time_embed[0](t_emb, act_out='silu'), res=lab, act_out='silu')
+        emb = None                              # (the blocks get SiLU(emb) and their own projection of it)
         # every res-block applies its own Linear(ted -> Cout) to the same SiLU(emb) (modules.py:754): one GEMM
         # against the row-concatenated weights instead of one launch per block
         emb_outs = self._all_emb_outs(emb_act)

@@ -242,15 +242,17 @@ class ResnetBlock(nn.Module):
         self.res_conv = _PointConv(dim_in, dim_out, 3) if dim_in != dim_out else nn.Identity()
 
     @torch.no_grad()
-    def forward(self, x, emb_act, gs=None, out=None):
-        """Row layout: emb_act = SiLU(time embedding) [B, emb_dim] (shared by all blocks of a step).
+    def forward(self, x, emb_act, gs=None, out=None, t=None):
+        """Row layout: emb_act = SiLU(time embedding) [B, emb_dim] (shared by all blocks of a step); ``t``: optional
+        precomputed time_mlp(emb) [B, dim_out] (the U-Net evaluates the time_mlp of ALL its blocks in one launch).
         Without ``gs``: the reference's ``forward(x, time_emb)`` (modules.py:505-513) on x [b, c, D, H, W] with the RAW
         time embedding (time_mlp's SiLU is applied here)."""
         if gs is None:
             rows, gs, back = _dense_io(x)
             return back(self.forward(rows, ops.act(emb_act.float().contiguous(), 'silu'), gs), gs.depth)
         h = self.block1[0](x, gs, act='silu')
-        t = self.time_mlp[1](emb_act)                       # [B, dim_out]
+        if t is None:
+            t = self.time_mlp[1](emb_act)                   # [B, dim_out]
         h = self.block1[2](h, gs, emb=t)                    # conv + bias + t[batch] fused
         h = self.block2[0](h, gs, act='silu', out=h)
         skip = x if isinstance(self.res_conv, nn.Identity) else self.res_conv(x)
@@ -364,12 +366,34 @@ class UNet3DModel(nn.Module):
     # ---- row-layout core ------------------------------------------------
     @torch.no_grad()
     def _embed(self, timesteps, label, batch_size):
-        emb = self.time_emb[0](self.time_pos_emb(timesteps.float()).contiguous())
-        emb = self.time_emb[2](ops.act(emb, 'silu'))
+        """SiLU(time_emb(time_pos_emb(t)) + label_emb(label)) [B, 4 mc] (graph_unet_lr.py:186-193): three launches."""
+        pe = ops.learned_sinusoid(timesteps.float(), self.time_pos_emb.weights)
+        lab = None
         if self.num_classes is not None:
             assert label.shape == (batch_size,)
-            emb = emb + self.label_emb(label)
-        return ops.act(emb, 'silu')
+            lab = self.label_emb(label)
+        return self.time_emb[2](self.time_emb[0](pe, act_out='silu'), res=lab, act_out='silu')
+
+    def _all_time_mlps(self, emb_act):
+        """{id(block): time_mlp(emb) [B, dim_out]} of every ResnetBlock from ONE launch on the row-concatenated
+        weights (every block applies its own Linear to the same SiLU(emb), modules.py:507-511)."""
+        blocks = [m for m in self.modules() if isinstance(m, ResnetBlock)]
+        lins = [b.time_mlp[1] for b in blocks]
+        key = tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version) for l in lins)
+        if getattr(self, '_tm_key', None) != key:
+            self._tm_w = torch.cat([l.weight.detach() for l in lins], dim=0).contiguous()
+            self._tm_b = torch.cat([l.bias.detach() for l in lins], dim=0).contiguous()
+            self._tm_pw = ops.PackedWeight()
+            self._tm_key = key
+        if ops.LINEAR_SMALL and emb_act.shape[0] <= 16:
+            allout = ops.linear_small(emb_act, self._tm_w, self._tm_b)
+        else:
+            allout = ops.gemm(emb_act, self._tm_pw.get(self._tm_w, 'nk'), self._tm_b)
+        outs, off = {}, 0
+        for b, l in zip(blocks, lins):
+            outs[id(b)] = allout[:, off:off + l.out_features]
+            off += l.out_features
+        return outs
 
     @torch.no_grad()
     def forward_rows(self, x, batch_size, timesteps, label=None, as_middle=False):
@@ -383,6 +407,7 @@ class UNet3DModel(nn.Module):
         if not as_middle:
             x = self.input_emb(x, gs)
         emb_act = self._embed(timesteps, label, batch_size)
+        tms = self._all_time_mlps(emb_act)
 
         # Zero-copy skip concatenation (as the sparse net does): the decoder level that consumes the skip tensor of
         # encoder level i reads ONE buffer [rows_i, C_x + C_skip]; the module that produces the skip writes its right
@@ -403,18 +428,19 @@ class UNet3DModel(nn.Module):
         for i, (resnet, self_attn, downsample) in enumerate(self.downs):
             slot = bufs[i][:, cout[i]:] if i in bufs else None
             if isinstance(self_attn, our_Identity):
-                x = resnet(x, emb_act, gs, out=slot)
+                x = resnet(x, emb_act, gs, out=slot, t=tms[id(resnet)])
             else:
-                x = run_attn(self_attn, resnet(x, emb_act, gs), gs, out=slot)
+                x = run_attn(self_attn, resnet(x, emb_act, gs, t=tms[id(resnet)]), gs, out=slot)
             if not isinstance(downsample, our_Identity):
                 x, gs = downsample(x, gs)
-        x = self.mid_block1(x, emb_act, gs)
+        x = self.mid_block1(x, emb_act, gs, t=tms[id(self.mid_block1)])
         x = run_attn(self.mid_self_attn, x, gs)
-        x = self.mid_block2(x, emb_act, gs, out=bufs[nlev - 1][:, :cout[nlev - 1]] if nlev > 1 else None)
+        x = self.mid_block2(x, emb_act, gs, out=bufs[nlev - 1][:, :cout[nlev - 1]] if nlev > 1 else None,
+                            t=tms[id(self.mid_block2)])
         for j, (resnet, self_attn, upsample) in enumerate(self.ups):
             i = nlev - 1 - j                                            # the encoder level whose skip this level consumes
             x = bufs[i]                                                 # = cat((x, skip_i), dim=1)
-            x = run_attn(self_attn, resnet(x, emb_act, gs), gs)
+            x = run_attn(self_attn, resnet(x, emb_act, gs, t=tms[id(resnet)]), gs)
             nxt = bufs[i - 1][:, :cout[i - 1]] if i - 1 in bufs else None
             x, gs = upsample(x, gs, out=nxt)
         x = self.end[0](x, gs, act='silu')

@@ -177,8 +177,15 @@ class _Linear(nn.Module):
         self._pw = ops.PackedWeight()
 
     @torch.no_grad()
-    def forward(self, x, res=None, out=None):
-        return ops.gemm(x, self._pw.get(self.weight, 'nk'), self.bias, res, out)
+    def forward(self, x, res=None, out=None, act_in=None, act_out=None):
+        """act_in / act_out: activation of the input / the result fused into the launch (few-row path) or run as
+        separate launches around the GEMM."""
+        if ops.LINEAR_SMALL and x.dim() == 2 and x.shape[0] <= 16:
+            return ops.linear_small(x, self.weight, self.bias, res, act_in, act_out, out)
+        if act_in is not None:
+            x = ops.act(x, act_in)
+        y = ops.gemm(x, self._pw.get(self.weight, 'nk'), self.bias, res, out)
+        return ops.act(y, act_out, out=y) if act_out is not None else y
 
 
 class Conv1x1(nn.Module):
@@ -240,8 +247,8 @@ class Downsample(nn.Module):
         return self._pw.get(self.weights.view(self.channels, self.channels * 8), 'nk')
 
     @torch.no_grad()
-    def forward(self, x, out=None, out_rows=None):
-        return ops.gemm(x.reshape(-1, self.channels * 8), self.packed(), out=out, out_rows=out_rows)
+    def forward(self, x, out=None, out_rows=None, out_planes=0):
+        return ops.gemm(x.reshape(-1, self.channels * 8), self.packed(), out=out, out_rows=out_rows, out_planes=out_planes)
 
     def extra_repr(self):
         return 'channels={}'.format(self.channels)
@@ -262,34 +269,49 @@ class Upsample(nn.Module):
         return self._pw.get(self.weights.view(self.channels, self.channels * 8), 'kn')
 
     @torch.no_grad()
-    def forward(self, x, a_rows=None, out=None):
-        y = ops.gemm(x, self.packed(), out=out, a_rows=a_rows)
+    def forward(self, x, a_rows=None, out=None, out_planes=0):
+        y = ops.gemm(x, self.packed(), out=out, a_rows=a_rows, out_planes=out_planes)
         return y.view(-1, self.channels) if out is None else out
 
     def extra_repr(self):
         return 'channels={}'.format(self.channels)
 
 
-def pool_nodes(x, doctree, d, downsample):
-    """Rows of graph depth d -> rows of depth d-1 (reference modules.py:409-423, without masks)."""
+def _planes_dst(n, C, planes, device):
+    """Destination of a pool / unpool when the following GraphConv wants operand planes: the copy and the GEMM epilogue
+    write hi / lo pairs straight into it (no fp32 tensor, no ofx_planes_split pass).  Returns (tensor, mode used)."""
+    out = torch.empty(n, C, dtype=torch.float32, device=device)
+    ok = ops.planes_pairs(planes) and C % 32 == 0 and out.data_ptr() % 128 == 0
+    return out, (planes if ok else 0)
+
+
+def pool_nodes(x, doctree, d, downsample, planes=0):
+    """Rows of graph depth d -> rows of depth d-1 (reference modules.py:409-423, without masks).  planes: pair-plane
+    mode the consumer takes (0: fp32 rows)."""
     copy_src, gemm_rows, n_out = doctree.pool_maps(d)
     C = x.shape[1]
     numd = int(doctree.nnum[d])
-    out = torch.empty(n_out, C, dtype=torch.float32, device=x.device)
-    ops.rows_copy(x, out, n_out, smap=copy_src)
-    downsample(x[x.shape[0] - numd:], out=out, out_rows=gemm_rows)
+    out, planes = _planes_dst(n_out, C, planes, x.device)
+    ops.rows_copy(x, out, n_out, smap=copy_src, planes=planes)
+    downsample(x[x.shape[0] - numd:], out=out, out_rows=gemm_rows, out_planes=planes)
+    if planes:
+        setattr(out, ops.PLANES_ATTR, planes)
     return out
 
 
-def unpool_nodes(x, doctree, d, upsample):
+def unpool_nodes(x, doctree, d, upsample, planes=0):
     """Rows of graph depth d -> rows of depth d+1 (reference modules.py:458-467)."""
     copy_src, a_rows, n_copy = doctree.unpool_maps(d)
     C = x.shape[1]
     n_ne = a_rows.numel()
-    out = torch.empty(n_copy + 8 * n_ne, C, dtype=torch.float32, device=x.device)
-    ops.rows_copy(x, out, n_copy, smap=copy_src)
+    out, planes = _planes_dst(n_copy + 8 * n_ne, C, planes, x.device)
+    if planes and n_ne and out[n_copy:].data_ptr() % 128:
+        planes = 0                                  # (C % 32 == 0 makes every row start a 128-B line: cannot happen)
+    ops.rows_copy(x, out, n_copy, smap=copy_src, planes=planes)
     if n_ne:
-        upsample(x, a_rows=a_rows, out=out[n_copy:].view(n_ne, 8 * C))
+        upsample(x, a_rows=a_rows, out=out[n_copy:].view(n_ne, 8 * C), out_planes=planes)
+    if planes:
+        setattr(out, ops.PLANES_ATTR, planes)
     return out
 
 
@@ -304,7 +326,8 @@ class GraphDownsample(nn.Module):
         self.conv = GraphConv(channels_in, channels_out, n_edge_type, avg_degree, n_node_type)
 
     def forward(self, x, doctree, d, out=None):
-        return self.conv(pool_nodes(x, doctree, d, self.downsample), doctree, d - 1, out=out, split_input=True)
+        return self.conv(pool_nodes(x, doctree, d, self.downsample, planes=self.conv.planes_mode(doctree, d - 1)),
+                         doctree, d - 1, out=out, split_input=True)
 
 
 class GraphUpsample(nn.Module):
@@ -318,7 +341,8 @@ class GraphUpsample(nn.Module):
         self.conv = GraphConv(channels_in, channels_out, n_edge_type, avg_degree, n_node_type)
 
     def forward(self, x, doctree, d, out=None):
-        return self.conv(unpool_nodes(x, doctree, d, self.upsample), doctree, d + 1, out=out, split_input=True)
+        return self.conv(unpool_nodes(x, doctree, d, self.upsample, planes=self.conv.planes_mode(doctree, d + 1)),
+                         doctree, d + 1, out=out, split_input=True)
 
 
 def graphnormalization(channels):

@@ -423,8 +423,9 @@ class PackedWeight:
         return self
 
 
-def gemm(a, pw, bias=None, res=None, out=None, a_rows=None, out_rows=None, m=None):
-    """out[orow(i)] = a[arow(i)] @ W + bias + res[i] (fp32 MFMA)."""
+def gemm(a, pw, bias=None, res=None, out=None, a_rows=None, out_rows=None, m=None, out_planes=0):
+    """out[orow(i)] = a[arow(i)] @ W + bias + res[i] (fp32 MFMA).  out_planes (2 / 3): the rows are written as hi / lo
+    pair planes (the operand format of the planes GraphConv) instead of fp32."""
     a, lda = _row_major(a)
     M = m if m is not None else (a_rows.numel() if a_rows is not None else a.shape[0])
     if a.shape[1] != pw.K:
@@ -442,13 +443,52 @@ def gemm(a, pw, bias=None, res=None, out=None, a_rows=None, out_rows=None, m=Non
     ws = workspace(a.device)
     _meta('dense_gemm', 2.0 * M * pw.K * pw.N, 4.0 * (M * pw.K + pw.K * pw.N + M * pw.N * (2 if res is not None else 1)),
           (M, pw.K, pw.N))
-    args = ('ofx_gemm_f32', ptr(a), lda, ptr(a_rows), M, pw.K, ptr(pw.t), pw.Kp, pw.N, ptr(bias),
-            ptr(res), ldr, ptr(out), ldc, ptr(out_rows), ptr(ws), ws.numel(), stream())
+    if out_planes:
+        args = ('ofx_gemm_f32_planes', ptr(a), lda, ptr(a_rows), M, pw.K, ptr(pw.t), pw.Kp, pw.N, ptr(bias),
+                ptr(res), ldr, ptr(out), ldc, ptr(out_rows), ptr(ws), ws.numel(), out_planes, stream())
+    else:
+        args = ('ofx_gemm_f32', ptr(a), lda, ptr(a_rows), M, pw.K, ptr(pw.t), pw.Kp, pw.N, ptr(bias),
+                ptr(res), ldr, ptr(out), ldc, ptr(out_rows), ptr(ws), ws.numel(), stream())
     if pw.N <= 64 or pw.K <= 64:
         with policy_scope('small_gemm'):
             call(*args)
     else:
         call(*args)
+    return out
+
+
+LINEAR_SMALL = True          # A/B switch: False sends the few-row linears through the MFMA GEMM again
+
+
+def linear_small(a, weight, bias=None, res=None, act_in=None, act_out=None, out=None):
+    """out = act_out(act_in(a) @ weight^T + bias + res) for a [M <= 16, K], weight [N, K] (nn.Linear layout, unpacked):
+    ONE launch, exact fp32 (ofx_linear_small)."""
+    a, lda = _row_major(a)
+    w, ldw = _row_major(weight.detach())
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and M <= 16
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    out2, ldo = _row_major(out)
+    assert out2 is out
+    ldr = 0
+    if res is not None:
+        res, ldr = _row_major(res)
+    _chk(bias)
+    _meta('small_linear', 2.0 * M * K * N, 4.0 * (N * K + M * K + M * N), (M, K, N))
+    call('ofx_linear_small', ptr(a), lda, M, K, ptr(w), ldw, N, ptr(bias.detach() if bias is not None else None), ptr(res),
+         ldr, ACT[act_in], ACT[act_out], ptr(out), ldo, stream())
+    return out
+
+
+def learned_sinusoid(t, w):
+    """[B, 2 * half + 1] = [t, sin(2 pi t w), cos(2 pi t w)] (LearnedSinusoidalPosEmb, modules.py:550-563)."""
+    _chk(t), _chk(w)
+    t, w = t.contiguous(), w.detach().contiguous()
+    out = torch.empty(t.shape[0], 2 * w.shape[0] + 1, dtype=torch.float32, device=t.device)
+    _meta('elementwise', 0, 4.0 * out.numel(), (out.numel(),))
+    call('ofx_learned_sinusoid', ptr(t), ptr(w), t.shape[0], w.shape[0], ptr(out), stream())
     return out
 
 
@@ -716,6 +756,7 @@ def gather_mean(x, seg_ptr, col):
 
 AUX_ATTR = '_ofx_aux'
 GN_FINALIZE_LAUNCH = False
+GN_FUSE_AUX_FINALIZE = False
 
 
 def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, act=None, out=None,
@@ -748,12 +789,14 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         _meta('gn_stats', 0, 4.0 * n * C, (n, C))
         call('ofx_gn_stats', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
     # mean / rstd are derived from the sums inside the apply launch (ofx.h: no ofx_gn_finalize launch) -- except when
-    # the launch also writes the consuming GraphConv's aux rows: those blocks normalise scattered source rows of any
-    # batch element, one (batch, group) statistic per thread, and pay for deriving it themselves (measured at depth 6,
-    # C = 128: 75 us fused vs 61 us with the 4.7 us finalize launch; without aux rows the fused launch is as fast as the
-    # plain one: profiles/r03/gn_probe.txt).  GN_FINALIZE_LAUNCH = True forces the separate launch everywhere (A/B).
+    # the launch also writes the consuming GraphConv's aux rows: an aux block's work is a chain of dependent loads
+    # (segment -> edge range -> column -> row) and deriving the statistics first makes the chain longer.  Measured twice:
+    # round 3, every aux thread deriving its own statistics: 75 us vs 61 us at depth 6, C = 128; round 4, once per aux
+    # block from its first / last segment's batch elements (the kernel still does that when no mean / rstd is passed):
+    # gn_apply 1.15 -> 1.47 ms per hr step, against 0.115 ms for the 18 finalize launches it removes.  So that case keeps
+    # the 4 us finalize launch.  GN_FINALIZE_LAUNCH = True forces it everywhere, GN_FUSE_AUX_FINALIZE = True removes it (A/B).
     mean = rstd = None
-    if GN_FINALIZE_LAUNCH or (planes and aux_graph is not None):
+    if GN_FINALIZE_LAUNCH or (planes and aux_graph is not None and not GN_FUSE_AUX_FINALIZE):
         mean = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
         rstd = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
         _meta('gn_finalize', 0, 24.0 * batch_size * C, (batch_size, C))
@@ -884,13 +927,17 @@ def cat_channels(a, b, buf=None):
     return out
 
 
-def rows_copy(src, dst, n, smap=None, dmap=None, C=None):
+def rows_copy(src, dst, n, smap=None, dmap=None, C=None, planes=0):
+    """dst[dmap(i)] = src[smap(i)]; planes (2 / 3): the destination rows are written as hi / lo pair planes."""
     src, lds = _row_major(src)
     dst2, ldd = _row_major(dst)
     assert dst2 is dst
     C = C if C is not None else src.shape[1]
     _meta('rows_copy', 0, 8.0 * n * C, (n, C))
-    call('ofx_rows_copy', ptr(src), lds, ptr(smap), ptr(dst), ldd, ptr(dmap), n, C, stream())
+    if planes:
+        call('ofx_rows_copy_planes', ptr(src), lds, ptr(smap), ptr(dst), ldd, ptr(dmap), n, C, planes, stream())
+    else:
+        call('ofx_rows_copy', ptr(src), lds, ptr(smap), ptr(dst), ldd, ptr(dmap), n, C, stream())
     return dst
 
 

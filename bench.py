@@ -686,6 +686,12 @@ def main():
                             'by a GroupNorm, the multi-neighbour pre-pass)')
         if tail:
             res_tail = tail_summary(tail, n_tail, peak, 1e3 * dt_tail / n_tail)
+        # the network's input / output convolutions (3 or 8 channels on one side) are gathers with almost no arithmetic:
+        # they are judged against HBM on their own line, not inside the matrix-bound aggregate
+        narrow = [r_ for r_ in per_layer(prof) if r_['layer'][0].startswith('graph') and min(r_['layer'][2], r_['layer'][3]) <= 8]
+        roof['narrow_graphconv_hbm'] = [{'layer': r_['layer'], 'launches': r_['launches'], 'avg_us': r_['avg_us'],
+                                         'algorithmic_GBps': r_['GBps'], 'peak': HBM_PEAK_GBS, 'frac': r_['GBps'] / HBM_PEAK_GBS,
+                                         'bound': 'hbm'} for r_ in narrow]
         roof['all_graphconv_launches'] = graph_only
         roof['gridconv_27tap_launches'] = grid_only
         res = {

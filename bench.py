@@ -351,6 +351,31 @@ def parity_spot_check(wl, dev):
         'rel_to_max_vs_oracle': err, 'bound': 1e-3}
 
 
+def mfma_sustained_probe(dev, steps=20000):
+    """The matrix-pipe rate this box SUSTAINS with realistic fp16 hi / lo operand pairs (csrc/ofx_probe.hip): the
+    data-sheet peak assumes the boost clock, which the chip only holds with constant operands."""
+    from octfusion_amd import _lib
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    ticks = torch.zeros(1, dtype=torch.int64, device=dev)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    args = (cus, _lib.ptr(sink), _lib.ptr(ticks), _lib.stream())
+    _lib.call('ofx_probe_mfma_sustained', steps // 10, *args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    _lib.call('ofx_probe_mfma_sustained', steps, *args)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    tf = cus * 8.0 * steps * 24 * 65536 / (ms * 1e-3) / 1e12
+    return {'issued_TFLOPs': tf, 'shader_clock_GHz': float(ticks.item()) / (ms * 1e6), 'ms': ms, 'steps': steps,
+            'what': 'v_mfma_f32_32x32x16_f16 x 24 per wave per step on four accumulators, 2 waves per SIMD on every CU, '
+                    'operands = fp16 hi / lo pairs of N(0,1)-like activations and of weights scaled into [2^14, 2^15) read '
+                    'from LDS (ds_read_b128), one s_barrier per step, NO global memory traffic: the ceiling the three-term '
+                    'contraction could reach on this box if everything but the MFMAs were free (csrc/ofx_probe.hip; '
+                    'constant operands reach 2.4 PFLOP/s at 2.3 GHz: profiles/r04/mfma_rate_probe.txt)'}
+
+
 def gather_microbench(doc, dev, C=128, iters=20):
     """Stand-alone segment-mean gather (the reference's col_data) at depth 6: HBM GB/s."""
     from octfusion_amd import ops
@@ -775,6 +800,16 @@ def main():
             ops.USE_PLANES = True
             _lib.call('ofx_set_gconv_persistent', 1)
         res['side_runs'] = extras
+        try:
+            sus = mfma_sustained_probe(dev)
+            roof = res['roofline']
+            roof['sustained'] = sus
+            if roof.get('bound') == 'mfma' and roof.get('achieved') and args.precision != 'fp32':
+                n_mfma = 3.0 if args.precision in ('fp16x3', 'bf16x3') else 1.0
+                roof['sustained']['roof_for_algorithmic_flops_TFLOPs'] = sus['issued_TFLOPs'] / n_mfma
+                roof['frac_of_sustained'] = roof['achieved'] * n_mfma / sus['issued_TFLOPs']
+        except Exception as e:      # noqa: BLE001
+            res['roofline']['sustained'] = {'error': str(e)}
 
         if wl.doc is not None and 6 in wl.doc._csr:
             res['gather'] = gather_microbench(wl.doc, dev)

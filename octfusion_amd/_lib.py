@@ -32,6 +32,7 @@ _SIGS = {
     'ofx_device_check': (c_i, [], False),
     'ofx_build_hash': (ctypes.c_char_p, [], False),
     'ofx_build_ablation': (c_i, [], False),
+    'ofx_probe_mfma_sustained': (c_i, [c_i, c_i, c_p, c_p, c_p], True),
     'ofx_scan_ws_bytes': (c_sz, [c_l], False),
     'ofx_scan_i32': (c_i, [c_p, c_p, c_l, c_p, c_p], True),
     'ofx_octree_full_layer': (c_i, [c_i, c_i, c_p, c_p, c_p], True),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence run on the GPU box: PMC passes over the planes-kernel probe, bench lines of the four BASELINE
 # workloads, rocprofv3 kernel stats of the default bench command (+ the gather microbenchmark row), the generate probe.
-# Everything lands under gpurun_out/final/; copy what is to be judged into profiles/r03/.
+# Everything lands under gpurun_out/final/; copy what is to be judged into profiles/r04/ (tools/collect_profiles.sh).
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=gpurun_out/final
@@ -14,7 +14,7 @@ for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_W
 done
 python tools/pmc_summary.py $OUT/pmc $OUT/pmc_traffic.json > $OUT/pmc_summary.log 2>&1
 # the bench lines below stamp roofline.traffic from this file (it carries the sha of the kernel sources it was measured on)
-mkdir -p profiles/r03 && cp $OUT/pmc_traffic.json profiles/r03/pmc_traffic.json
+mkdir -p profiles/r04 && cp $OUT/pmc_traffic.json profiles/r04/pmc_traffic.json
 timeout 400 python bench.py --steps 20 --warmup 5 --layers > $OUT/bench_hr.json 2> $OUT/bench_hr.err
 for w in lr hr_cond feature; do
   timeout 400 python bench.py --workload $w --layers > $OUT/bench_$w.json 2> $OUT/bench_$w.err
@@ -25,6 +25,10 @@ done
   python $OLDPWD/tools/gather_probe.py > $OLDPWD/$OUT/gather_under_rocprof.json 2> $OLDPWD/$OUT/rocprof_gather.err)
 find $OUT/prof $OUT/prof_gather -name "*kernel_trace.csv" -delete
 timeout 600 python tools/generate_probe.py --out $OUT/generate_probe.json > $OUT/generate_probe.log 2>&1
+timeout 300 python tools/checkpoint_memory_probe.py --out $OUT/checkpoint_memory.json > $OUT/checkpoint_memory.log 2>&1
+./tools/probes/mfma_rate > $OUT/mfma_rate_probe.txt 2>&1
+for w in hr lr; do python tools/step_trace.py --workload $w --out $OUT/step_trace_$w.json > /dev/null 2>&1; done
+python tools/step_trace.py --workload hr --batch 1 --out $OUT/step_trace_hr_b1.json > /dev/null 2>&1
 python - <<'PY'
 import json
 for w in ('hr', 'lr', 'hr_cond', 'feature'):

@@ -109,6 +109,7 @@ class Workload:
             self.shape = (batch, 8, 16, 16, 16)
         g = torch.Generator().manual_seed(1 + rank)
         self.x = torch.randn(self.shape, generator=g).to(dev)
+        self.x_init = self.x.clone()
         self.label = (torch.arange(batch) % 5).to(dev) if w['label'] else None
         self.nested = getattr(self.net, NESTED[self.stage]) if NESTED[self.stage] else None
         times = sampler.sampling_times(200)
@@ -121,7 +122,20 @@ class Workload:
         self.x_self = None
         self.sampler = sampler
 
+    RESET_EVERY = 50
+
+    def reset_input(self, i):
+        """With random weights the DDIM update is not a denoiser: |x| grows a few per cent per step (hr_cond: x 1.065),
+        and after a few hundred steps the residual stream leaves the range real sampling lives in (and the fp16 operand
+        range: NaN by design, include/ofx.h).  The state is therefore re-drawn every RESET_EVERY steps -- one N x 3 copy,
+        outside the K-step region the driver times (steps W+1 .. W+K with K <= 50 never cross a reset)."""
+        if i % self.RESET_EVERY == 0 and i > 0:
+            self.x.copy_(self.x_init)
+            if self.x_self is not None:
+                self.x_self = None
+
     def step(self, i):
+        self.reset_input(i)
         i = i % 200
         noise = None
         if self.df == 'x0' and float(self.coef_host[i, 3]) != 0.0:
@@ -367,7 +381,7 @@ def mfma_sustained_probe(dev, steps=20000):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    tf = cus * 8.0 * steps * 24 * 65536 / (ms * 1e-3) / 1e12
+    tf = cus * 8.0 * steps * 24 * 32768 / (ms * 1e-3) / 1e12        # 32 x 32 x 16 x 2 flops per MFMA
     return {'issued_TFLOPs': tf, 'shader_clock_GHz': float(ticks.item()) / (ms * 1e6), 'ms': ms, 'steps': steps,
             'what': 'v_mfma_f32_32x32x16_f16 x 24 per wave per step on four accumulators, 2 waves per SIMD on every CU, '
                     'operands = fp16 hi / lo pairs of N(0,1)-like activations and of weights scaled into [2^14, 2^15) read '
@@ -599,6 +613,10 @@ def main():
 
             def replay(first, n):
                 for i in range(first, first + n):
+                    if i % wl.RESET_EVERY == 0 and i > 0:
+                        wl.x.copy_(wl.x_init)
+                        if self_s is not None:
+                            self_s.zero_()
                     j = i % 200
                     cond_s.copy_(wl.cond[j].expand(batch))
                     coef_s.copy_(wl.coef[j])

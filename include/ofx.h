@@ -68,7 +68,7 @@ int ofx_set_range_words(uint32_t* words);
  * device with realistic fp16 hi / lo operand pairs from LDS and no memory traffic -- ~1.45 PFLOP/s at ~1.55 GHz on MI355X
  * against the 2.5 PFLOP/s data-sheet peak, which needs constant operands (power limit).  One launch of `steps`
  * 24-MFMA steps per wave, 8 waves per block, `blocks` blocks (0: one per compute unit); the caller times it.
- * flops = blocks * 8 * steps * 24 * 65536; ticks[0] = shader clocks block 0 spent in the loop. */
+ * flops = blocks * 8 * steps * 24 * 32768; ticks[0] = shader clocks block 0 spent in the loop. */
 int ofx_probe_mfma_sustained(int steps, int blocks, float* sink, unsigned long long* ticks, void* stream);
 
 /* ------------------------------------------------------------------ scans */

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(512, 2) mfma_sustained_kernel(int steps, float
 }
 
 // One launch of `steps` 24-MFMA steps per wave on `blocks` 512-thread blocks (0: one per compute unit).  The caller
-// times it (events on `stream`): flops = blocks * 8 waves * steps * 24 * 65536; ticks[0] = s_memtime ticks of block 0
+// times it (events on `stream`): flops = blocks * 8 waves * steps * 24 * 32768; ticks[0] = s_memtime ticks of block 0
 // (shader clocks: ticks / seconds = the clock the pipe ran at).  sink: >= 1 float, ticks: >= 1 uint64, both device.
 extern "C" int ofx_probe_mfma_sustained(int steps, int blocks, float* sink, unsigned long long* ticks, void* stream) {
   if (steps < 1 || !sink || !ticks) return OFX_EINVAL;

@@ -391,6 +391,10 @@ int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes,
  *      itself in modes 2 and 3.  With aux != NULL (then out must not alias x) the same launch also writes the consuming
  *      GraphConv's aux rows (zero row + multi-neighbour means, from the CSR seg_ptr / col / multi_seg of that
  *      graph depth), and ofx_graphconv_fwd_planes is called with aux_ready = 1: one launch less per convolution.
+ *      aux_plan (optional, with aux): which block writes which aux row -- int32 [mb + 1] ptr (mb = ceil(n / 64) blocks
+ *      of 64 consecutive rows) | ptr[mb] aux row ids 1..n_multi grouped by the block that holds ALL their source rows |
+ *      aux_left | aux_left leftover ids (sources in several blocks; always contains the zero row 0).  A block then
+ *      writes its aux rows right after its own rows, from L1 / L2 instead of a second trip to HBM.
  * ofx_pack_weights_planes: GraphConv weights [7*(cin+nt'), cout] (element (k, n) at W[k*sk + n*sn]) ->
  *      [k tile][cout][128-B line], k order: 7*cin gathered channels direction-major, then the 7*nt node-type
  *      rows zero-padded to a whole tile; ofx_planes_packed_bytes() bytes.
@@ -420,7 +424,8 @@ int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C, const int
                         const float* rstd, const double* sums, const float* count, int groups, float eps,
                         float count_eps, const float* w, const float* bias, int act, int mode, void* out,
                         int64_t ldo_bytes, const int32_t* seg_ptr, const int32_t* col, const int32_t* multi_seg,
-                        int64_t n_multi, void* aux /* optional */, void* stream);
+                        int64_t n_multi, void* aux /* optional */, const int32_t* aux_plan /* optional */,
+                        int64_t aux_left, void* stream);
 int64_t ofx_planes_packed_ktiles(int cin, int nt, int mode);
 int64_t ofx_planes_packed_bytes(int cin, int nt, int cout, int mode);
 int ofx_pack_weights_planes(const float* W, int64_t sk, int64_t sn, int cin, int nt, int cout, int mode, void* out,

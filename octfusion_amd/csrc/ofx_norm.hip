@@ -198,16 +198,30 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ seg_ptr,
                                                        const int32_t* __restrict__ col,
                                                        const int32_t* __restrict__ multi_seg, int64_t n_multi,
-                                                       char* __restrict__ aux) {
+                                                       char* __restrict__ aux, const int32_t* __restrict__ aux_plan) {
   const int CT = C >> 2, RP = 256 / CT;
   const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
   __shared__ float fin_ms[FIN ? 2 * 2 * 1024 : 1];       // [slot][mean | rstd][C]
+  // owned aux rows of this block (aux_plan): row id, segment size and up to four source rows each, fetched at block START
+  // by one thread per aux row -- the dependent chain plan -> multi_seg -> seg_ptr -> col runs under the main rows, and
+  // the aux phase at the end is ONE load stage deep (<= 64 owned rows per block: a block has 64 rows, every aux row has
+  // >= 2 sources in it)
+  constexpr int AUX_LDS = 64;
+  __shared__ int aux_v[AUX_LDS], aux_n[AUX_LDS], aux_src[AUX_LDS][4];
   int fb0 = -1, fb1 = -1;
-  const bool is_aux = (int64_t)blockIdx.x < aux_blocks;
+  // aux blocks are INTERLEAVED with the main blocks in dispatch order (block i is the a-th aux block if the running
+  // share i * A / T steps at i): both kinds are then resident together for the whole launch, and the aux blocks'
+  // dependent-load chains run under the main blocks' streaming.  (Until round 4 the aux blocks were the FIRST A blocks of
+  // the grid: 4 400 of them at depth 6 against 2 048 resident block slots, so they ran alone, latency-bound, before any
+  // main block started -- 16 % more rows cost 42-50 % more time: 42.7 -> 63.7 us at depth 6, C = 128.)
+  const int64_t gT = gridDim.x;
+  const int64_t a_before = aux_blocks > 0 ? ((int64_t)blockIdx.x * aux_blocks) / gT : 0;
+  const bool is_aux = aux_blocks > 0 && (((int64_t)blockIdx.x + 1) * aux_blocks) / gT > a_before;
+  const int64_t aux_id = a_before, main_id = (int64_t)blockIdx.x - a_before;
   // the first four rows of this thread are requested BEFORE the statistics are finalised: the rows come from HBM, the
   // sums from L2, and the block would otherwise sit through a chain of dependent loads + fp64 arithmetic + a barrier
   // before its first payload byte is even asked for (measured: +23 % on the whole launch)
-  const int64_t r_begin0 = ((int64_t)blockIdx.x - aux_blocks) * GN_APPLY_ROWS;
+  const int64_t r_begin0 = main_id * GN_APPLY_ROWS;
   const int64_t r_end0 = r_begin0 + GN_APPLY_ROWS < n ? r_begin0 + GN_APPLY_ROWS : n;
   const bool pre = FIN && !is_aux && rl < RP && r_begin0 + rl + 3 * (int64_t)RP < r_end0;
   float4 pv0, pv1, pv2, pv3;
@@ -229,7 +243,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
       // aux rows are ordered by segment = row * 7 + direction, i.e. by row, i.e. by batch element, and every source of
       // a segment lies in the batch element of its row: the block's aux rows span the batch elements of its first and
       // last segment's rows (two dependent loads; the zero row v = 0 needs no statistics)
-      const int64_t v0 = (int64_t)blockIdx.x * RP, v1e = v0 + RP - 1 < n_multi ? v0 + RP - 1 : n_multi;
+      const int64_t v0 = aux_id * RP, v1e = v0 + RP - 1 < n_multi ? v0 + RP - 1 : n_multi;
       if (n_multi > 0) {
         fb0 = bid[multi_seg[(v0 > 0 ? v0 : 1) - 1] / 7];
         fb1 = bid[multi_seg[(v1e > 0 ? v1e : 1) - 1] / 7];
@@ -248,7 +262,24 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
     }
     __syncthreads();
   }
-  if (rl >= RP) return;
+  int own_b = 0, own_e = 0;
+  if (!is_aux && aux && aux_plan && MODE != 0) {
+    const int64_t mb_ = (n + GN_APPLY_ROWS - 1) / GN_APPLY_ROWS;
+    own_b = aux_plan[main_id]; own_e = aux_plan[main_id + 1];
+    const int i = own_b + (int)threadIdx.x;
+    if (i < own_e && (int)threadIdx.x < AUX_LDS) {
+      const int v = aux_plan[mb_ + 1 + i];
+      const int64_t sgm = multi_seg[v - 1];
+      const int32_t pa = seg_ptr[sgm], pz = seg_ptr[sgm + 1];
+      aux_v[threadIdx.x] = v;
+      aux_n[threadIdx.x] = pz - pa;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) aux_src[threadIdx.x][k] = col[pa + k < pz ? pa + k : pa];
+      if (pz - pa > 4) aux_n[threadIdx.x] = -(int)(pa + 1);          // long segment: walked through col at the end
+    }
+  }
+  // (threads beyond the last whole row lane -- 256 % (C / 4) != 0 -- take no part, but stay for the barrier below)
+  const bool active = rl < RP;
   const int c = cl * 4;
   const float4 ww = *reinterpret_cast<const float4*>(w + c);
   const float4 bb = *reinterpret_cast<const float4*>(bias + c);
@@ -301,14 +332,10 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
       *reinterpret_cast<uint2*>(orow + c * 2) = o;
     }
   };
-  if (is_aux) {
-    // ---- aux rows of the consuming GraphConv (its multi-neighbour pre-pass, folded into this launch): aux[0] = the
-    // zero row, aux[1 + v] = mean over segment multi_seg[v] of the NORMALISED source rows.  Reads the raw x (complete
-    // before this launch), so it does not depend on the main blocks -- out must not alias x when aux is requested.
-    // One aux row per (thread row lane): these are chains of dependent loads (segment -> column -> batch id -> row),
-    // so they get many small blocks at the FRONT of the grid and finish under the streaming main blocks.
-    const int64_t v = (int64_t)blockIdx.x * RP + rl;
-    if (v > n_multi) return;
+  // ---- aux rows of the consuming GraphConv (its multi-neighbour pre-pass, folded into this launch): aux[0] = the zero
+  // row, aux[1 + v] = mean over segment multi_seg[v] of the NORMALISED source rows.  Reads the raw x (complete before
+  // this launch), so it does not depend on the main blocks -- out must not alias x when aux is requested.
+  auto aux_row = [&](int64_t v) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (v > 0) {
       const int64_t sgm = multi_seg[v - 1];
@@ -337,10 +364,29 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
       acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
     }
     store(aux + v * ldo, acc);
+  };
+  // aux_plan (optional, int32): [mb + 1] ptr | owned list (ptr[mb] aux row ids, grouped by the MAIN block -- 64
+  // consecutive rows -- that holds ALL sources of the row) | n_left | n_left leftover ids (sources in several blocks,
+  // and the zero row 0).  A main block writes its owned aux rows right after its own rows, while their sources are still
+  // in its L1 / the XCD's L2: the four fine neighbours of a coarse leaf's face are siblings, i.e. rows of one aligned
+  // group of eight.  Without a plan every aux row is a leftover (round 3: 16 % more rows cost 42-50 % more time, because
+  // the aux blocks re-read their source rows from HBM at another time than the main pass).
+  const int64_t mb = (n + GN_APPLY_ROWS - 1) / GN_APPLY_ROWS;
+  if (is_aux) {
+    if (!active) return;
+    const int64_t idx = aux_id * RP + rl;
+    if (aux_plan) {
+      const int32_t n_own = aux_plan[mb];
+      const int32_t n_left = aux_plan[mb + 1 + n_own];
+      if (idx < n_left) aux_row(aux_plan[mb + 2 + n_own + idx]);
+    } else if (idx <= n_multi) {
+      aux_row(idx);
+    }
     return;
   }
   const int64_t r_begin = r_begin0, r_end = r_end0;
   int64_t r = r_begin + rl;
+  if (active) {
   if (pre) {
     store(out + r * ldo, norm(pb0, pv0));
     store(out + (r + RP) * ldo, norm(pb1, pv1));
@@ -360,6 +406,62 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
     store(out + (r + 3 * RP) * ldo, norm(b3, v3));
   }
   for (; r < r_end; r += RP) store(out + r * ldo, norm(bid[r], *reinterpret_cast<const float4*>(x + r * ldx + c)));
+  }
+  if (aux && aux_plan && MODE != 0) {
+    // the aux rows whose sources all lie in this block's 64 rows: averaged from the OUTPUT this block has just written
+    // (hi + lo re-assembled: 3 instructions per element instead of the ~25 of normalise + SiLU -- GroupNorm-apply is as
+    // much VALU- as HBM-bound, and re-normalising four sources per aux row cost 42-50 % on top of the main pass for 16 %
+    // more rows).  Same values as the stand-alone pre-pass of the planes GraphConv (planes_multi_mean_kernel).
+    const int32_t pb = own_b, pe_ = own_e;
+    if (pb < pe_) {
+      __syncthreads();                   // (workgroup-scope fence: this block's stores to `out` and the LDS index rows)
+      auto joined = [&](int64_t sr) {
+        const char* orow = out + sr * ldo;
+        float4 y;
+        if (MODE == 2 || MODE == 3) {
+          const char* o = orow + (c >> 5) * 128 + (c & 31) * 2;
+          const uint2 hi = *reinterpret_cast<const uint2*>(o), lo = *reinterpret_cast<const uint2*>(o + 64);
+          g2_join2(MODE, hi.x, lo.x, y.x, y.y);
+          g2_join2(MODE, hi.y, lo.y, y.z, y.w);
+        } else {
+          const uint2 hv = *reinterpret_cast<const uint2*>(orow + c * 2);
+          y.x = g2_f16_lo(hv.x); y.y = g2_f16_hi(hv.x); y.z = g2_f16_lo(hv.y); y.w = g2_f16_hi(hv.y);
+        }
+        return y;
+      };
+      if (active) {
+        for (int32_t i = rl; i < pe_ - pb; i += RP) {
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          int64_t v;
+          float inv;
+          if (i < AUX_LDS && aux_n[i] > 0) {
+            v = aux_v[i];
+            const int cnt = aux_n[i];
+            float4 y[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = joined(aux_src[i][k]);           // four rows in flight
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float wgt = k < cnt ? 1.f : 0.f;
+              acc.x += wgt * y[k].x; acc.y += wgt * y[k].y; acc.z += wgt * y[k].z; acc.w += wgt * y[k].w;
+            }
+            inv = 1.f / (float)cnt;
+          } else {                                                            // (> 64 owned rows or a long segment)
+            v = aux_plan[mb + 1 + pb + i];
+            const int64_t sgm = multi_seg[v - 1];
+            const int32_t pa = seg_ptr[sgm], pz = seg_ptr[sgm + 1];
+            for (int32_t p = pa; p < pz; ++p) {
+              const float4 y = joined(col[p]);
+              acc.x += y.x; acc.y += y.y; acc.z += y.z; acc.w += y.w;
+            }
+            inv = 1.f / (float)(pz - pa);
+          }
+          acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+          store(aux + v * ldo, acc);
+        }
+      }
+    }
+  }
 }
 
 // mean / rstd: from ofx_gn_finalize -- or both NULL with (sums, count, groups, eps, count_eps): finalised on the fly.
@@ -385,11 +487,11 @@ extern "C" int ofx_gn_apply(const float* x, int64_t ldx, int64_t n, int C, const
     if (mean)
       gn_apply_kernel<0, false><<<(int)mb, 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, batch_id, mean, rstd, f, w, bias, act,
                                                                          (char*)out, ldo * 4, 0, nullptr, nullptr,
-                                                                         nullptr, 0, nullptr);
+                                                                         nullptr, 0, nullptr, nullptr);
     else
       gn_apply_kernel<0, true><<<(int)mb, 256, 0, ofx_stream(stream)>>>(x, ldx, n, C, batch_id, nullptr, nullptr, f, w, bias,
                                                                         act, (char*)out, ldo * 4, 0, nullptr, nullptr,
-                                                                        nullptr, 0, nullptr);
+                                                                        nullptr, 0, nullptr, nullptr);
   }
   OFX_LAUNCH_CHECK();
   return OFX_OK;
@@ -399,7 +501,8 @@ extern "C" int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C
                                    const float* mean, const float* rstd, const double* sums, const float* count,
                                    int groups, float eps, float count_eps, const float* w, const float* bias, int act,
                                    int mode, void* out, int64_t ldo_bytes, const int32_t* seg_ptr, const int32_t* col,
-                                   const int32_t* multi_seg, int64_t n_multi, void* aux, void* stream) {
+                                   const int32_t* multi_seg, int64_t n_multi, void* aux, const int32_t* aux_plan,
+                                   int64_t aux_left, void* stream) {
   const int chunk = g2_pairs(mode) ? 32 : 64;
   GnFin f = {nullptr, nullptr, 1, eps, count_eps};
   if (mode < 1 || mode > 3 || !x || !batch_id || !w || !bias || !out || n < 0 || C < chunk ||
@@ -408,16 +511,18 @@ extern "C" int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C
       ((uintptr_t)bias & 15) || act < 0 || act > 2 || !gn_fin_args(mean, rstd, sums, count, C, groups, f))
     return OFX_EINVAL;
   if (aux && (!seg_ptr || !col || n_multi < 0 || (n_multi > 0 && !multi_seg) || ((uintptr_t)aux & 127) ||
-              (const void*)out == (const void*)x))
+              (const void*)out == (const void*)x || (aux_plan && (aux_left < 1 || aux_left > n_multi + 1))))
     return OFX_EINVAL;
   if (n > 0) {
     const int64_t mb = ofx_cdiv(n, GN_APPLY_ROWS);
-    const int64_t ab = aux ? ofx_cdiv(n_multi + 1, 256 / (C >> 2)) : 0;      // one aux row per row lane
+    // one aux row per row lane; with a plan only the leftover rows (aux_left of them, incl. the zero row) need blocks
+    const int64_t ab = aux ? ofx_cdiv(aux_plan ? aux_left : n_multi + 1, 256 / (C >> 2)) : 0;
     const int grid = (int)(mb + ab);
     hipStream_t st = ofx_stream(stream);
 #define GN_GO(M_, F_)                                                                                              \
   gn_apply_kernel<M_, F_><<<grid, 256, 0, st>>>(x, ldx, n, C, batch_id, mean, rstd, f, w, bias, act, (char*)out,   \
-                                                ldo_bytes, ab, seg_ptr, col, multi_seg, n_multi, (char*)aux)
+                                                ldo_bytes, ab, seg_ptr, col, multi_seg, n_multi, (char*)aux,       \
+                                                aux ? aux_plan : nullptr)
     if (mode == 2) { if (mean) GN_GO(2, false); else GN_GO(2, true); }
     else if (mode == 3) { if (mean) GN_GO(3, false); else GN_GO(3, true); }
     else { if (mean) GN_GO(1, false); else GN_GO(1, true); }

@@ -213,6 +213,44 @@ class DualOctree:
         """(nbr_ext int32 [N*7], multi_seg int32 [V], V): the branch-free gather table (ofx.h)."""
         return self._ext[d]
 
+    def aux_plan(self, d, rows_per_block=64):
+        """(plan int32, leftover count) for ofx_gn_apply_planes: which 64-row block of the GroupNorm launch writes which
+        aux row of graph depth d (include/ofx.h).  An aux row = the mean over a multi-neighbour segment; its sources are
+        the finer neighbours across one face of a coarse leaf -- siblings, i.e. rows of one aligned group of eight -- so
+        almost every aux row has all its sources inside one block, which then writes it from cache right after its own
+        rows.  Built once per doctree depth (a few torch index ops, no host sync beyond the sizes)."""
+        key = ('aux_plan', d, rows_per_block)
+        if key in self._ext:
+            return self._ext[key]
+        seg_ptr, col, N, E = self.csr(d)
+        _, multi_seg, V = self.ext(d)
+        dev = seg_ptr.device
+        mb = (N + rows_per_block - 1) // rows_per_block
+        if V == 0:
+            plan = torch.cat([torch.zeros(mb + 1, dtype=torch.int32, device=dev),
+                              torch.tensor([1, 0], dtype=torch.int32, device=dev)])
+            self._ext[key] = (plan, 1)
+            return self._ext[key]
+        ms = multi_seg[:V].long()
+        start, end = seg_ptr[ms].long(), seg_ptr[ms + 1].long()
+        lens = end - start
+        seg_of_edge = torch.repeat_interleave(torch.arange(V, device=dev), lens)
+        edge = torch.repeat_interleave(start - torch.cumsum(lens, 0) + lens, lens) + torch.arange(int(lens.sum()), device=dev)
+        src_blk = col[edge].long() // rows_per_block
+        lo = torch.full((V,), mb, dtype=torch.long, device=dev).scatter_reduce_(0, seg_of_edge, src_blk, 'amin')
+        hi = torch.full((V,), -1, dtype=torch.long, device=dev).scatter_reduce_(0, seg_of_edge, src_blk, 'amax')
+        owned = lo == hi
+        ids = torch.arange(1, V + 1, device=dev)
+        own_ids, own_blk = ids[owned], lo[owned]
+        order = torch.argsort(own_blk, stable=True)
+        counts = torch.bincount(own_blk, minlength=mb)
+        ptr_ = torch.zeros(mb + 1, dtype=torch.long, device=dev)
+        ptr_[1:] = torch.cumsum(counts, 0)
+        left = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), ids[~owned]])
+        plan = torch.cat([ptr_, own_ids[order], torch.tensor([left.numel()], device=dev), left]).to(torch.int32)
+        self._ext[key] = (plan, int(left.numel()))
+        return self._ext[key]
+
     def rev(self, d):
         """Reverse graph of depth d for GraphConv's backward pass (ofx.h): dict with rev_ptr [N*7+1], rev_row [E],
         rev_w [E] (1 / size of the forward segment the edge came from), nbr (primary table), nbr_ext, multi_seg, V.

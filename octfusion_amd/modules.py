@@ -150,7 +150,7 @@ class DualOctreeGroupNorm(nn.Module):
         if planes:
             seg_ptr, col, _, _ = doctree.csr(depth)
             _, multi_seg, n_multi = doctree.ext(depth)
-            aux_graph = (seg_ptr, col, multi_seg, n_multi)
+            aux_graph = (seg_ptr, col, multi_seg, n_multi, doctree.aux_plan(depth) if ops.AUX_PLAN else None)
         y = ops.group_norm(data, doctree.batch_id32(depth), doctree.count(depth), doctree.batch_size,
                            self.weights, self.bias, self.group, self.eps, act, out, stats=stats, planes=planes,
                            aux_graph=aux_graph)

@@ -756,7 +756,8 @@ def gather_mean(x, seg_ptr, col):
 
 AUX_ATTR = '_ofx_aux'
 GN_FINALIZE_LAUNCH = False
-GN_FUSE_AUX_FINALIZE = False
+GN_FUSE_AUX_FINALIZE = os.environ.get('OFX_GN_FUSE_AUX_FINALIZE', '0') == '1'
+AUX_PLAN = os.environ.get('OFX_AUX_PLAN', '1') == '1'                 # aux rows written by the main block that holds their sources (A/B: False = separate aux blocks)
 
 
 def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, act=None, out=None,
@@ -811,15 +812,17 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         if aux_graph is not None and out is not None and out.data_ptr() == x.data_ptr():
             out = None
         out, ldo = _planes_out(n, C, planes, dev, out if planes_pairs(planes) else None)
-        aux = seg_ptr = col = multi_seg = None
-        n_multi = 0
+        aux = seg_ptr = col = multi_seg = plan = None
+        n_multi = n_left = 0
         if aux_graph is not None:
-            seg_ptr, col, multi_seg, n_multi = aux_graph
+            seg_ptr, col, multi_seg, n_multi = aux_graph[:4]
+            if len(aux_graph) > 4 and aux_graph[4] is not None and AUX_PLAN:
+                plan, n_left = aux_graph[4]          # (int32 plan, leftover count): dual_octree.DualOctree.aux_plan
             aux = torch.empty((n_multi + 1) * ldo, dtype=torch.uint8, device=dev)
         _meta('gn_apply', 0, 8.0 * n * C + (n_multi + 1) * float(ldo), (n, C, 'planes+aux' if aux is not None else 'planes'))
         call('ofx_gn_apply_planes', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(sums), ptr(count), groups, eps,
              count_eps, ptr(w), ptr(b), ACT[act], planes, ptr(out), ldo, ptr(seg_ptr), ptr(col), ptr(multi_seg), n_multi,
-             ptr(aux), stream())
+             ptr(aux), ptr(plan), n_left, stream())
         setattr(out, PLANES_ATTR, planes)
         if aux is not None:
             setattr(out, AUX_ATTR, aux)

@@ -28,6 +28,17 @@ for d, C in [(6, 128), (6, 256), (6, 384), (5, 256), (5, 512), (4, 512)]:
     t0 = timeit(lambda: f())
     t2 = timeit(lambda: f(planes=2))
     t2a = timeit(lambda: f(planes=2, aux_graph=(seg_ptr, col, multi_seg, V)))
+    plan = doc.aux_plan(d)
+    t2p = timeit(lambda: f(planes=2, aux_graph=(seg_ptr, col, multi_seg, V, plan)))
+    ya = f(planes=2, aux_graph=(seg_ptr, col, multi_seg, V))
+    yb = f(planes=2, aux_graph=(seg_ptr, col, multi_seg, V, plan))
+    def aux_vals(y):
+        a_ = getattr(y, ops.AUX_ATTR).view(torch.float32).view(V + 1, -1)[:, :C]
+        setattr(a_, ops.PLANES_ATTR, 2)
+        return ops.planes_merge(a_, 2)
+    diff = float((aux_vals(ya) - aux_vals(yb)).abs().max())
+    print('   aux rows by owner block (plan): %.1f us vs separate aux blocks %.1f us; leftover rows %d of %d; main rows equal %s, '
+          'aux rows max |diff| %.2e' % (t2p, t2a, plan[1], V + 1, torch.equal(ya, yb), diff))
     # A/B: the separate ofx_gn_finalize launch (round 2) vs mean / rstd derived inside the apply launch (round 3)
     ops.GN_FINALIZE_LAUNCH = True
     t2a_sep = timeit(lambda: f(planes=2, aux_graph=(seg_ptr, col, multi_seg, V)))

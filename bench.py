@@ -679,7 +679,7 @@ def main():
                     % {'fp16x3': (3, 'fp16x3 (three fp16 MFMAs per product)'), 'bf16x3': (2, 'bf16x3'), 'fp16': (1, 'fp16')}[bf])
         if dom is None:         # exact-fp32 mode / dense lr stage: the register-staged kernel carries the time
             dom = profile_summary(prof, dt_prof, ('graph', 'grid'), peak)
-            dom_name = 'gemm_fast_kernel / gemm_bf16x3_kernel<MODE_GATHER> (register-staged fused GraphConv / 27-tap gridconv)'
+            dom_name = 'gemm_fast_kernel / gemm_pairs_x3_kernel<MODE_GATHER> (register-staged fused GraphConv / 27-tap gridconv)'
         graph_only = profile_summary(prof, dt_prof, ('graph', 'graph2', 'graph2h'), peak)
         grid_only = profile_summary(prof, dt_prof, ('grid',), peak)
         roof = {'kernel': dom_name}

@@ -11,7 +11,7 @@
 // into the LDS A-tile.
 //
 // Precisions (ofx_set_precision): 0 (default) = bf16x3: both operands split into bf16 hi + lo, three
-// v_mfma_f32_32x32x16_bf16 per product term, fp32 accumulate (gemm_bf16x3_kernel; ~1e-5 of an fp32 reference);
+// v_mfma_f32_32x32x16_bf16 per product term, fp32 accumulate (gemm_pairs_x3_kernel; ~1e-5 of an fp32 reference);
 // 1 = exact fp32: v_mfma_f32_32x32x2_f32, a k-ordered fma chain (gemm_fast_kernel / gemm_kernel; 157 TF peak).
 // Tiling (wave = 64): block = 4 waves, BM = 128 rows, BK = 32; BN = 128 (2x2 waves of 64x64), 64 (2x2 of 64x32) or
 // 32 (4x1 of 32x32).  Weights are pre-packed once (ofx_pack_weights / ofx_pack_conv3d): fp32 [k/4][n][4] followed by
@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(const GemmArgs g) {
   if (g_begin < g_end) {
     int32_t ia0, ia1, ia2, ia3, ib0, ib1, ib2, ib3;
     {
-      // iteration order: channel chunk outer, direction inner (see gemm_bf16x3_kernel)
+      // iteration order: channel chunk outer, direction inner (see gemm_pairs_x3_kernel)
       const int d0 = g_begin % ndir;
       const int d1 = (g_begin + 1 < nkt_g ? g_begin + 1 : nkt_g - 1) % ndir;
       if (MODE == MODE_DENSE) {
@@ -580,8 +580,9 @@ __device__ __forceinline__ f32x16 mfma16(u32x4h a, u32x4h b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8h_t, a), __builtin_bit_cast(f16x8h_t, b), c, 0, 0, 0);
 }
 
+// (named gemm_bf16x3_kernel until round 4; it has run fp16 pairs -- H16 = 1, the default precision -- since round 3)
 template <int MODE, int WM, int WN, int MI, int NI, int H16>
-__global__ void __launch_bounds__(256, 2) gemm_bf16x3_kernel(const GemmArgs g) {
+__global__ void __launch_bounds__(256, 2) gemm_pairs_x3_kernel(const GemmArgs g) {
   // LDS carries only the A tile (hi and lo planes, [128][32+8] bf16 each, double buffered = 40 KB).
   // The weight fragments go global(L2) -> registers directly in MFMA operand layout (the packed
   // [k/8][n][8] planes give every lane one contiguous 16-B read).  Staging the weight tile through LDS
@@ -1038,9 +1039,9 @@ static int launch_bf16x3_h(GemmArgs& g, hipStream_t st) {
   constexpr size_t lds = 2 * (2 * BM * 80);
   static bool attr_set[OFX_MAX_DEVICES] = {};
   if (lds > 64 * 1024 &&      // e.g. 68 KB for BN = 128: above the 64 KB default cap
-      !ofx_raise_lds_limit(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<MODE, WM, WN, MI, NI, H16>), (int)lds, attr_set))
+      !ofx_raise_lds_limit(reinterpret_cast<const void*>(&gemm_pairs_x3_kernel<MODE, WM, WN, MI, NI, H16>), (int)lds, attr_set))
     return OFX_ELAUNCH;
-  gemm_bf16x3_kernel<MODE, WM, WN, MI, NI, H16><<<g.ntm * g.ntn * g.nsplit, 256, lds, st>>>(g);
+  gemm_pairs_x3_kernel<MODE, WM, WN, MI, NI, H16><<<g.ntm * g.ntn * g.nsplit, 256, lds, st>>>(g);
   return OFX_OK;
 }
 template <int MODE, int WM, int WN, int MI, int NI>

@@ -674,6 +674,7 @@ def main():
         peak = PEAKS[bf]
         planes_kind = {'fp16x3': 'graph2', 'bf16x3': 'graph2', 'fp16': 'graph2h'}.get(bf)
         dom = profile_summary(prof, dt_prof, (planes_kind,), peak) if planes_kind else None
+        dom_is_planes = dom is not None
         dom_name = ('gconv3_kernel<%d,*,*> (fused GraphConv on operand planes, persistent stream-K blocks: LDS-DMA gather '
                     '-> %s MFMA, fp32 accumulate; gconv2_kernel for the layers too small for it)'
                     % {'fp16x3': (3, 'fp16x3 (three fp16 MFMAs per product)'), 'bf16x3': (2, 'bf16x3'), 'fp16': (1, 'fp16')}[bf])
@@ -696,7 +697,7 @@ def main():
                          'traffic': None})
             roof.update(dom)
             tpath = PMC_FILE
-            if os.path.exists(tpath):
+            if dom_is_planes and os.path.exists(tpath):       # (the counters are the planes GraphConv's: nothing to say about the dense lr stage)
                 try:
                     pj = json.load(open(tpath))
                     want_k = {'fp16x3': 'gconv3_kernel<3,', 'bf16x3': 'gconv3_kernel<2,', 'fp16': 'gconv3_kernel<1,'}.get(bf)

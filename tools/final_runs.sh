@@ -26,6 +26,7 @@ done
 find $OUT/prof $OUT/prof_gather -name "*kernel_trace.csv" -delete
 timeout 600 python tools/generate_probe.py --out $OUT/generate_probe.json > $OUT/generate_probe.log 2>&1
 timeout 300 python tools/checkpoint_memory_probe.py --out $OUT/checkpoint_memory.json > $OUT/checkpoint_memory.log 2>&1
+[ -x tools/probes/mfma_rate ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o tools/probes/mfma_rate tools/probes/mfma_rate.hip
 ./tools/probes/mfma_rate > $OUT/mfma_rate_probe.txt 2>&1
 for w in hr lr; do python tools/step_trace.py --workload $w --out $OUT/step_trace_$w.json > /dev/null 2>&1; done
 python tools/step_trace.py --workload hr --batch 1 --out $OUT/step_trace_hr_b1.json > /dev/null 2>&1

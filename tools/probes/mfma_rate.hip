@@ -156,17 +156,20 @@ __global__ void __launch_bounds__(512, 2) power(int steps, const char* src, size
       if constexpr (LEVEL >= 2) {
         // the real loop reads the NEXT half step's 12 fragments while this half's MFMAs run
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < (LEVEL == 6 ? 2 : 4); ++k) {
           asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[half ^ 1][k]) : "v"(ro + half * 4096), "n"(0));
           asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[half ^ 1][k]) : "v"(ro + half * 4096), "n"(16384));
         }
         // (four extra reads: the real loop has 12 per half step, this has 8 -> add 4)
       }
-      if constexpr (LEVEL >= 3) {
+      if constexpr (LEVEL >= 3 && LEVEL != 6) {
         if (half == 0) {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            const size_t o = (goff + (size_t)k * 1024) % src_bytes;
+          for (int k = 0; k < (LEVEL == 5 ? 4 : 6); ++k) {
+            // LEVEL 3: a stream through the whole buffer (HBM); LEVEL >= 4: every wave re-reads its own 12 KB (3 MB per XCD:
+            // L2 hits, the regime of the real kernel, whose gathered lines are 7x re-used across the directions)
+            const size_t o = LEVEL == 3 ? (goff + (size_t)k * 1024) % src_bytes
+                                        : ((size_t)blockIdx.x * 8 + wid) * 12288 + (size_t)(s & 1) * 6144 + (size_t)k * 1024 + lane * 16;
             __builtin_amdgcn_global_load_lds((gcp)src + o, (ldsp)(lds + 96 * 1024 + wid * 6144 + k * 1024), 16, 0, 0);
           }
           goff += stride;
@@ -185,7 +188,7 @@ __global__ void __launch_bounds__(512, 2) power(int steps, const char* src, size
           }
       if constexpr (LEVEL >= 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (half == 0) {
-        if constexpr (LEVEL >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (LEVEL >= 3 && LEVEL != 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
       }
     }
@@ -203,9 +206,8 @@ __global__ void __launch_bounds__(512, 2) power(int steps, const char* src, size
   if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
 template <int LEVEL, int FILL = 0, bool BF16 = false>
-static void gop(const char* name, int steps) {
+static void gop(const char* name, int steps, size_t nb = (size_t)1 << 30) {
   float* o; unsigned long long* tk; char* src;
-  const size_t nb = (size_t)1 << 30;
   hipMalloc(&o, 64); hipMalloc(&tk, 8 * 256); hipMalloc(&src, nb);
   hipMemset(src, 0x3c, nb);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&power<LEVEL, FILL, BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -231,6 +233,9 @@ int main() {
   gop<2, 1, true>("operands from LDS, REALISTIC bf16 hi/lo pairs", 40000);
   gop<2, 0, true>("operands from LDS, random bits, bf16 MFMA", 40000);
   gop<3>("+ global_load_lds 6 KB / wave / step (L2/HBM -> LDS)", 10000);
+  gop<4, 1, false>("realistic pairs + LDS reads + DMA 6 KB/wave/step, L2-HOT source (16 MB)", 20000, (size_t)32 << 20);
+  gop<5, 1, false>("realistic pairs + LDS reads + DMA 4 KB/wave/step, L2-hot (the 256x256-tile ratio)", 20000, (size_t)32 << 20);
+  gop<6, 1, false>("realistic pairs + HALF the LDS reads, no DMA (128x128 wave tiles)", 20000);
 
   const int S = 20000;
   go<false, false, false>("VGPR acc, MFMA only", 512, 256, S);

@@ -811,9 +811,12 @@ static int g3_auto_wm(int64_t M, int cout, int nkt, int ni) {
   if (g3_wm_pref == 2 || g3_wm_pref == 4) return g3_wm_pref;
   // 256-row tiles (one block per CU) won on every layer of the hr workload, 3-14 % over the 128-row geometry
   // (profiles/r03/gconv3_ab_shell6_b8.json): fewer operand bytes per MFMA, and the persistent loop already hides
-  // what the second co-resident block used to hide.  Layers with too few units for 256-row pieces take 128 rows.
+  // what the second co-resident block used to hide.  Layers with few k-step units are latency-bound instead (a block's
+  // share is the 16-step minimum whatever the geometry): half-size k-steps halve that latency.  One-shape step trace,
+  // round 4 (tools/step_trace.py --batch 1 --tile 0 / 2): 960 units 46.8 -> 37.4 us, 1 920: 47.0 -> 39.2, 1 856: 52.4 ->
+  // 42.8, 3 030: 49.8 -> 48.5, 3 712: 54.0 -> 55.3, 7 296: 70.8 -> 72.4, 8 686: 77.3 -> 79.1.
   const int64_t U4 = ofx_cdiv(M, 256) * ofx_cdiv(cout, 64 * ni) * nkt;
-  return U4 >= 64 * 8 ? 4 : 2;
+  return U4 >= 3500 ? 4 : 2;
 }
 // persistent stream-K kernel (ofx_gemm3.hip); returns 1 when the shape / workspace does not qualify
 int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, size_t ws_tail_bytes, void* sync,

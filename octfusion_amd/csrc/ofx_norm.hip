@@ -22,12 +22,12 @@ constexpr int GN_ROWS_PER_BLOCK = 64;
 // to stream) and own proportionally more consecutive rows.
 // Small tensors (the 16 MB concat in the middle of the hr net: 32 768 rows x 128, batch 8) are the other end of the
 // same trade: 64-row blocks put 64 atomics on every address -- 13 us of serialised atomics for 3 us of reading
-// (28 us per call in the round-4 step trace) -- so a block also owns at least ~128 KB of rows (>= 8 blocks per batch
+// (28 us per call in the round-4 step trace) -- so a block also owns at least ~512 KB of rows (>= 8 blocks per batch
 // element are kept so that the read still spreads over the chip).
 static inline int64_t gn_stats_rows(int64_t n, int batch_size, int C = 128) {
   const int64_t chunks = (n + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK;
   const int64_t bytes_per_batch = n * (int64_t)C * 4 / (batch_size > 0 ? batch_size : 1);
-  int64_t per_batch = bytes_per_batch / (128 << 10);
+  int64_t per_batch = bytes_per_batch / (512 << 10);
   per_batch = per_batch < 8 ? 8 : (per_batch > 128 ? 128 : per_batch);
   int64_t cap = per_batch * (int64_t)batch_size;
   if (cap < 64) cap = 64;

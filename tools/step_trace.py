@@ -19,11 +19,13 @@ ap.add_argument('--workload', default='hr')
 ap.add_argument('--batch', type=int, default=None)
 ap.add_argument('--out', default=None)
 ap.add_argument('--steps', type=int, default=3)
+ap.add_argument('--tile', type=int, default=0, help='force the planes-kernel geometry (2 / 4; 0 = automatic)')
 a = ap.parse_args()
 torch.set_grad_enabled(False)
 dev = torch.device('cuda:0')
 _lib.require_device()
 ops.set_precision('fp16x3')
+_lib.call('ofx_set_gconv2_tile', a.tile)
 w = bench.WORKLOADS[a.workload]
 wl = bench.Workload(a.workload, a.batch or w['batch'], dev, 0)
 wl.run(0, 4)

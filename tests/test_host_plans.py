@@ -1,0 +1,95 @@
+"""Host-side planning logic that needs no GPU: the aux-row plan of the GroupNorm launch (dual_octree.DualOctree.aux_plan:
+which 64-row block writes which multi-neighbour mean row, include/ofx.h ofx_gn_apply_planes) on synthetic CSR graphs,
+and the quota-aware CPU baseline sizing of bench.py."""
+import random
+import types
+
+import torch
+
+
+def _stub(seg_ptr, col, multi_seg, N):
+    from octfusion_amd.dual_octree import DualOctree
+    s = types.SimpleNamespace()
+    s._ext = {}
+    s.csr = lambda d: (seg_ptr, col, N, int(col.numel()))
+    s.ext = lambda d: (None, multi_seg, int(multi_seg.numel()))
+    s.aux_plan = lambda d, rows_per_block=64: DualOctree.aux_plan(s, d, rows_per_block)
+    return s
+
+
+def _random_graph(N, seed):
+    rnd = random.Random(seed)
+    seg_ptr, col, multi = [0], [], []
+    for s in range(N * 7):
+        k = rnd.choice([0, 1, 1, 1, 2, 4, 4, 5, 9])
+        if k > 1 and rnd.random() < 0.8:                       # siblings: consecutive rows of one aligned group of eight
+            base = rnd.randrange(0, max(1, N // 8)) * 8
+            rows = [min(N - 1, base + j) for j in rnd.sample(range(8), min(k, 8))]
+        else:
+            rows = [rnd.randrange(N) for _ in range(k)]
+        col += sorted(rows)
+        seg_ptr.append(len(col))
+        if k > 1:
+            multi.append(s)
+    return (torch.tensor(seg_ptr, dtype=torch.int32), torch.tensor(col, dtype=torch.int32),
+            torch.tensor(multi, dtype=torch.int32))
+
+
+def test_aux_plan_partitions_the_aux_rows_by_owner_block():
+    for N, seed in ((1, 0), (70, 1), (700, 2), (1000, 3)):
+        seg_ptr, col, multi_seg = _random_graph(N, seed)
+        V = int(multi_seg.numel())
+        if V == 0:
+            continue
+        plan, n_left = _stub(seg_ptr, col, multi_seg, N).aux_plan(5)
+        plan = plan.tolist()
+        mb = (N + 63) // 64
+        ptr = plan[:mb + 1]
+        n_own = ptr[mb]
+        owned = plan[mb + 1:mb + 1 + n_own]
+        assert plan[mb + 1 + n_own] == n_left
+        left = plan[mb + 2 + n_own:]
+        assert len(left) == n_left and left[0] == 0                       # the zero row is always a leftover
+        assert ptr[0] == 0 and all(a <= b for a, b in zip(ptr, ptr[1:]))
+        assert sorted(owned + left) == list(range(V + 1))                 # every aux row exactly once
+        for blk in range(mb):
+            for v in owned[ptr[blk]:ptr[blk + 1]]:
+                s = int(multi_seg[v - 1])
+                srcs = col[int(seg_ptr[s]):int(seg_ptr[s + 1])].tolist()
+                assert all(r // 64 == blk for r in srcs), (blk, v, srcs)  # all sources inside the owner's 64 rows
+        for v in left[1:]:
+            s = int(multi_seg[v - 1])
+            srcs = col[int(seg_ptr[s]):int(seg_ptr[s + 1])].tolist()
+            assert len({r // 64 for r in srcs}) > 1                       # leftovers really span blocks
+    # no multi-neighbour segment at all: only the zero row, as a leftover
+    seg_ptr = torch.arange(0, 7 * 10 + 1, dtype=torch.int32)
+    col = torch.zeros(70, dtype=torch.int32)
+    plan, n_left = _stub(seg_ptr, col, torch.zeros(0, dtype=torch.int32), 10).aux_plan(4)
+    assert n_left == 1 and plan.tolist() == [0, 0, 1, 0]
+
+
+def test_cpu_baseline_sizes_itself_inside_the_cgroup_quota(tmp_path, monkeypatch):
+    import bench
+    q = bench.cgroup_cpu_quota()
+    assert q is None or q > 0
+    # the parsing of both cgroup layouts
+    import builtins
+    real_open = builtins.open
+    files = {'/sys/fs/cgroup/cpu.max': '1600000 100000\n'}
+
+    def fake_open(path, *a, **k):
+        if path in files:
+            p = tmp_path / 'f'
+            p.write_text(files[path])
+            return real_open(p, *a, **k)
+        if str(path).startswith('/sys/fs/cgroup/'):
+            raise OSError
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, 'open', fake_open)
+    assert bench.cgroup_cpu_quota() == 16.0
+    files['/sys/fs/cgroup/cpu.max'] = 'max 100000\n'
+    assert bench.cgroup_cpu_quota() is None
+    del files['/sys/fs/cgroup/cpu.max']
+    files['/sys/fs/cgroup/cpu/cpu.cfs_quota_us'] = '400000\n'
+    files['/sys/fs/cgroup/cpu/cpu.cfs_period_us'] = '100000\n'
+    assert bench.cgroup_cpu_quota() == 4.0

@@ -756,6 +756,10 @@ def gather_mean(x, seg_ptr, col):
 
 AUX_ATTR = '_ofx_aux'
 GN_FINALIZE_LAUNCH = False
+# dense grids with at least this many rows per batch element take the statistics + apply pair instead of the one-launch
+# kernel (whose grid is batch x channel slices: 32 blocks for 16^3 x 64 at batch 8) -- A/B: OFX_GN_ROWS_TWO_KERNELS
+# (round 4, same box, same run: lr stage 1.052 -> 1.015 ms per step, hr 8.80 -> 8.74 with 2048 = the 16^3 level)
+GN_ROWS_TWO_KERNELS = int(os.environ.get('OFX_GN_ROWS_TWO_KERNELS', '2048'))
 GN_FUSE_AUX_FINALIZE = os.environ.get('OFX_GN_FUSE_AUX_FINALIZE', '0') == '1'
 AUX_PLAN = os.environ.get('OFX_AUX_PLAN', '1') == '1'                 # aux rows written by the main block that holds their sources (A/B: False = separate aux blocks)
 
@@ -771,7 +775,8 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
     n, C = x.shape
     dev = x.device
     range_words(dev)
-    if rows_per_batch is not None and stats is None and not planes and rows_per_batch * (C // groups) <= (1 << 16):
+    if (rows_per_batch is not None and stats is None and not planes and rows_per_batch * (C // groups) <= (1 << 16)
+            and rows_per_batch < GN_ROWS_TWO_KERNELS):
         assert n == rows_per_batch * batch_size
         if out is None:
             out = torch.empty(n, C, dtype=torch.float32, device=dev)

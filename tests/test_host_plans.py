@@ -93,3 +93,28 @@ def test_cpu_baseline_sizes_itself_inside_the_cgroup_quota(tmp_path, monkeypatch
     files['/sys/fs/cgroup/cpu/cpu.cfs_quota_us'] = '400000\n'
     files['/sys/fs/cgroup/cpu/cpu.cfs_period_us'] = '100000\n'
     assert bench.cgroup_cpu_quota() == 4.0
+
+
+def test_whole_box_cpu_workers_orchestration(monkeypatch):
+    """bench.cpu_baseline's multi-process figure (pinned workers, file rendezvous, summed rates) on this host, with
+    4-thread workers so that two of them fit: the dense lr stage, 1 warm-up + 2 timed steps each."""
+    import os
+    import bench
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    q = bench.cgroup_cpu_quota()
+    if q is not None:
+        usable = min(usable, int(q + 0.5))
+    if usable < 8:
+        import pytest
+        pytest.skip('needs 8 usable CPUs for two 4-thread workers')
+    monkeypatch.setenv('OFX_CPU_WORKER_THREADS', '4')
+    monkeypatch.setitem(bench.WORKLOADS['lr'], 'cpu', (2, 3))
+    r = bench.cpu_baseline('lr', 4)
+    assert r['usable_cpus'] == usable and r['threads_used'] == min(32, usable) and r['single_process']['value'] > 0
+    wb = r['whole_box']
+    assert wb['processes'] == min(8, usable // 4) and wb['threads_per_process'] == 4 and wb['value'] > 0
+    assert len(wb['timed_s_per_worker']) == wb['processes'] and wb['common_window_s'] > 0
+    assert r['value'] >= max(r['single_process']['value'], 0) * 0.999 or r['value'] == wb['value']

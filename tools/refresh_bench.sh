@@ -1,3 +1,4 @@
+# Re-take the hr / lr bench lines and the rocprofv3 kernel stats of the default bench command (a subset of final_runs.sh).
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=gpurun_out/final2

@@ -532,16 +532,26 @@ def main():
     from octfusion_amd import dist
     rank, local_rank, world = dist.init('gloo' if args.bootstrap_only and not torch.cuda.is_available() else None)
     if args.bootstrap_only:
+        # rendezvous + every collective kind the timed run depends on (broadcast, MAX reduction, all-gather, barrier),
+        # the rank table and the shard rule for 64 shapes (train.py:166-185) -- no HIP call; gloo on a CPU-only machine
         t = torch.full((4,), float(rank))
         if torch.cuda.is_available():
             t = t.cuda(local_rank)
         import torch.distributed as td
+        table = [(rank, local_rank, str(t.device))]
         if world > 1:
             td.broadcast(t, src=0)
+            table = [None] * world
+            td.all_gather_object(table, (rank, local_rank, str(t.device)))
         mx = dist.max_over_ranks(float(rank), t.device)
+        per_rank = dist.gather_floats(float(len(dist.shard_indices(64, rank, world))), t.device)
         if rank == 0:
-            emit(json.dumps({'bootstrap': 'ok', 'world': world, 'max_rank_seen': mx, 'shard_of_10': dist.shard_indices(10, 0, world)}))
+            emit(json.dumps({'bootstrap': 'ok', 'world': world, 'max_rank_seen': mx, 'broadcast_value': float(t[0]),
+                             'shard_of_10': dist.shard_indices(10, 0, world),
+                             'ranks': [list(r_) for r_ in table], 'shapes_of_64_per_rank': per_rank,
+                             'shard_of_64_last_rank': dist.shard_indices(64, world - 1, world)}))
         dist.barrier()
+        dist.shutdown()
         return
     rccl_note = None
     if world == 1 and torch.cuda.is_available():
@@ -606,7 +616,7 @@ def main():
                     gstep()
                     gstep()
                 torch.cuda.current_stream().wait_stream(side_s)
-                with torch.cuda.graph(gph):
+                with torch.cuda.graph(gph, stream=side_s):      # the warm-up stream: its scratch exists already (ops._no_capture)
                     out = gstep()
                 return gph, out
             graphs = {sign: capture(sign) for sign in sorted(set(wl.sign if is_lr else [False]))}

@@ -378,6 +378,27 @@ int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes,
                       double* stats /* optional */, int64_t stats_ld,
                       void* ws, size_t ws_bytes, void* stream);
 
+/* The two GraphConvs of a diffusion U-Net that are gathers, not contractions (csrc/ofx_narrow.hip), same operator
+ * (modules.py:194-220), raw nn.Parameter weights W [7 * (cin + nt), cout] row-major (no packing):
+ *  ofx_graphconv_narrow_in: the INPUT convolution (graph_unet_hr.py:116), cin <= 8 channels -> cout in {64, 128},
+ *      7 * (cin + nt) <= 96.  col_data of a 64-row block in LDS, a lane owns 1-2 output columns with its weights in
+ *      registers, exact fp32 FMA; `stats` as in ofx_graphconv_fwd (ws >= ceil(n / 64) * cout * 8 bytes of partials).
+ *      type_frac = the fp32 slab of ofx_graph_type_frac ([n, ldt], entry dir * nt + t), NULL when nt == 0.
+ *  ofx_graphconv_narrow_out: the OUTPUT convolution (graph_unet_hr.py:205-209), C channels -> cout <= 8, as
+ *      project-then-aggregate (scatter_mean and the weight product commute): the caller first computes the dense
+ *      P = y @ Wd with Wd = ofx_narrow_out_pack(W) ([C, pw], Wd[c, dir * cout + o] = W[dir * (C + nt) + c, o], pw >= 7 cout
+ *      zero-padded: 32 or 64 so that a row of P is whole 128-B lines), then this call gathers cout floats per edge:
+ *      out[r, o] = sum_dir mean_{e in seg(r, dir)} P[col[e], dir * cout + o] + sum_{dir, t} type_frac[r, dir * nt + t] *
+ *      W[dir * (C + nt) + C + t, o] + bias[o]. */
+int ofx_graphconv_narrow_in(const float* x, int64_t ldx, int cin, int64_t n_nodes, const int32_t* seg_ptr,
+                            const int32_t* col, const float* type_frac, int64_t ldt, int nt, const float* W, int cout,
+                            const float* bias, const int32_t* batch_id, float* out, int64_t ldc,
+                            double* stats /* optional */, int64_t stats_ld, void* ws, size_t ws_bytes, void* stream);
+int ofx_narrow_out_pack(const float* W, int C, int nt, int cout, int pw, float* Wd, void* stream);
+int ofx_graphconv_narrow_out(const float* P, int64_t ldp, int cout, int64_t n_nodes, const int32_t* seg_ptr,
+                             const int32_t* col, const float* type_frac, int64_t ldt, int nt, const float* W, int C,
+                             const float* bias, float* out, int64_t ldc, void* stream);
+
 /* ---------------------------------------------------------------- GraphConv on operand planes
  * Second implementation of the same operator (modules.py:194-220) for the layers that carry the step's
  * time: operands arrive PRE-SPLIT and are staged global -> LDS by DMA (csrc/ofx_gemm2.hip).
@@ -426,6 +447,9 @@ int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C, const int
                         int64_t ldo_bytes, const int32_t* seg_ptr, const int32_t* col, const int32_t* multi_seg,
                         int64_t n_multi, void* aux /* optional */, const int32_t* aux_plan /* optional */,
                         int64_t aux_left, void* stream);
+/* rows per main block of ofx_gn_apply_planes: the granularity `aux_plan` is built for (the host-side plan builder,
+ * octfusion_amd/dual_octree.py aux_plan, asks instead of assuming). */
+int ofx_gn_apply_rows(void);
 int64_t ofx_planes_packed_ktiles(int cin, int nt, int mode);
 int64_t ofx_planes_packed_bytes(int cin, int nt, int cout, int mode);
 int ofx_pack_weights_planes(const float* W, int64_t sk, int64_t sn, int cin, int nt, int cout, int mode, void* out,

@@ -24,7 +24,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'libofx.so')
 SOURCES = ['ofx_octree.hip', 'ofx_graph.hip', 'ofx_gemm.hip', 'ofx_gemm2.hip', 'ofx_gemm3.hip', 'ofx_norm.hip',
-           'ofx_dense.hip', 'ofx_misc.hip', 'ofx_loss.hip', 'ofx_points.hip', 'ofx_probe.hip']
+           'ofx_dense.hip', 'ofx_misc.hip', 'ofx_loss.hip', 'ofx_points.hip', 'ofx_probe.hip', 'ofx_narrow.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
 

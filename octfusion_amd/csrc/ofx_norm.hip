@@ -497,6 +497,8 @@ extern "C" int ofx_gn_apply(const float* x, int64_t ldx, int64_t n, int C, const
   return OFX_OK;
 }
 
+extern "C" int ofx_gn_apply_rows(void) { return GN_APPLY_ROWS; }
+
 extern "C" int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,
                                    const float* mean, const float* rstd, const double* sums, const float* count,
                                    int groups, float eps, float count_eps, const float* w, const float* bias, int act,

@@ -42,9 +42,8 @@ def init(backend=None, force=False):
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
         s.close()
-        if backend == 'nccl':
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+        dist.init_process_group(backend=backend, init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                                **_device_kw(backend, local_rank))
         _FORCED = True
         return rank, local_rank, world
     if world > 1 and not dist.is_initialized():
@@ -52,10 +51,19 @@ def init(backend=None, force=False):
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'      # "nccl" is RCCL on ROCm
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        if backend == 'nccl':
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **_device_kw(backend, local_rank))
     return rank, local_rank, world
+
+
+def _device_kw(backend, local_rank):
+    """RCCL: bind the group to this rank's GPU at creation (`device_id`) -- the communicator is then created eagerly, on
+    the right device, instead of lazily by the first collective on "the device under the current context" (torch's
+    warning in the round-4 driver log; with 8 ranks a rank whose current device is still 0 at that moment would put two
+    ranks on one GPU)."""
+    if backend != 'nccl':
+        return {}
+    torch.cuda.set_device(local_rank)
+    return {'device_id': torch.device('cuda', local_rank)}
 
 
 def shard_indices(n_items, rank, world):
@@ -97,27 +105,29 @@ def _pg_device():
     return torch.device('cpu')
 
 
-_VERIFIED_SETS = set()
+_SIGNATURES = {}
 
 
 def _check_gradient_set(grads, keys):
     """Ranks with different key sets / sizes would pack different flat buckets: an RCCL hang or silent corruption.
     ONE tiny all-reduce -- MAX over [sig, -sig], i.e. max and min at once -- of (key count, total elements, a checksum
-    over every `name:numel` pair) turns that into an error.  A set that was verified once is not checked again (the
-    parameters of a model do not change between steps): the check costs a collective + a host read only on the first
-    step and when the set changes."""
+    over every `name:numel` pair) turns that into an error.  EVERY rank issues it on EVERY call (a skip
+    decided from rank-local state is itself a collective mismatch the moment the sets diverge -- the rank whose set
+    changed would all-reduce six int64 words against its peers' first fp32 bucket); only the signature of a set seen
+    before is cached.  Cost per training step: one 48-byte collective + one host read, against a 40-300 ms step."""
     import zlib
     ident = tuple((k, grads[k].numel()) for k in keys)
-    if ident in _VERIFIED_SETS:
-        return
-    sig = [len(keys), sum(n for _, n in ident), sum(zlib.crc32(('%s:%d' % kn).encode()) for kn in ident) % (1 << 40)]
+    sig = _SIGNATURES.get(ident)
+    if sig is None:
+        sig = [len(keys), sum(n for _, n in ident), sum(zlib.crc32(('%s:%d' % kn).encode()) for kn in ident) % (1 << 40)]
+        if len(_SIGNATURES) < 64:
+            _SIGNATURES[ident] = sig
     t = torch.tensor(sig + [-v for v in sig], dtype=torch.int64, device=_pg_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     hi, lo = t[:3].tolist(), [-v for v in t[3:].tolist()]
     if hi != lo:
         raise RuntimeError('all_reduce_mean_: the ranks hold different gradient sets (keys / sizes: min %s, max %s) -- a '
                            'parameter without gradient on some rank must be zero-filled by the caller' % (lo, hi))
-    _VERIFIED_SETS.add(ident)
 
 
 @torch.no_grad()
@@ -181,7 +191,10 @@ def gather_floats(value, device, force=False):
 
 def barrier(force=False):
     if _active(force):
-        dist.barrier()
+        if dist.get_backend() == 'nccl':
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def shutdown():

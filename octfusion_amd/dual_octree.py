@@ -123,6 +123,9 @@ class DualOctree:
     def _adopt(self, prev, d, unpool_ok):
         for name in ('_csr', '_nbr', '_ext', '_bid32', '_ntype8', 'batch_id_dict', '_count'):
             getattr(self, name)[d] = getattr(prev, name)[d]
+        for key, v in prev._ext.items():                # aux plans of the adopted depth (keyed ('aux_plan', d, rows))
+            if isinstance(key, tuple) and key[0] == 'aux_plan' and key[1] == d:
+                self._ext[key] = v
         if d in prev._rev:
             self._rev[d] = prev._rev[d]
         g = _Graph(self, d)
@@ -213,12 +216,14 @@ class DualOctree:
         """(nbr_ext int32 [N*7], multi_seg int32 [V], V): the branch-free gather table (ofx.h)."""
         return self._ext[d]
 
-    def aux_plan(self, d, rows_per_block=64):
+    def aux_plan(self, d, rows_per_block=None):
         """(plan int32, leftover count) for ofx_gn_apply_planes: which 64-row block of the GroupNorm launch writes which
         aux row of graph depth d (include/ofx.h).  An aux row = the mean over a multi-neighbour segment; its sources are
         the finer neighbours across one face of a coarse leaf -- siblings, i.e. rows of one aligned group of eight -- so
         almost every aux row has all its sources inside one block, which then writes it from cache right after its own
         rows.  Built once per doctree depth (a few torch index ops, no host sync beyond the sizes)."""
+        if rows_per_block is None:
+            rows_per_block = _lib.lib().ofx_gn_apply_rows()          # the kernel's own block size (never assumed)
         key = ('aux_plan', d, rows_per_block)
         if key in self._ext:
             return self._ext[key]

@@ -49,6 +49,7 @@ class GraphConv(nn.Module):
         self.reset_parameters()
         self._pw = ops.PackedWeight()
         self._pw2 = ops.PackedPlanes()
+        self._pno = ops.PackedNarrowOut()
         self.emit_stats = True
 
     def planes_mode(self, doctree, d, cin=None):
@@ -90,6 +91,19 @@ class GraphConv(nn.Module):
             stats = ops.stats_zeros(doctree.batch_size * self.out_channels * 2, x.device)
         mode = ops.planes_of(x)
         cin_k = self.in_channels
+        if not mode and emb is None and res is None:
+            # the two gather-shaped layers of a U-Net (csrc/ofx_narrow.hip): its input and its output convolution
+            if ops.narrow_in_ok(self.in_channels, self.out_channels, nt):
+                y = ops.graphconv_narrow_in(x, seg_ptr, col, self.weights, self.in_channels, nt,
+                                            doctree.type_frac(d, nt) if nt else None, self.bias if self.use_bias else None,
+                                            doctree.batch_id32(d) if stats is not None else None, out, stats)
+                if stats is not None:
+                    setattr(y, ops.STATS_ATTR, stats)
+                return y
+            if ops.NARROW_OUT and self.out_channels <= 8 and self.in_channels % 32 == 0 and N >= 4096:
+                return ops.graphconv_narrow_out(x, seg_ptr, col, self._pno.get(self.weights, self.in_channels, nt),
+                                                self.in_channels, nt, doctree.type_frac(d, nt) if nt else None,
+                                                self.bias if self.use_bias else None, out)
         if not mode and split_input:
             mode = self.planes_mode(doctree, d)
             if mode:

@@ -290,8 +290,19 @@ def sync_words(device):
     key = (device.type, device.index, _stream_id(device))
     t = _SYNC.get(key)
     if t is None:
+        _no_capture('the flag words')
         t = _SYNC[key] = torch.zeros(SYNC_WORDS, dtype=torch.int32, device=device)
     return t
+
+
+def _no_capture(what):
+    """Per-stream scratch must exist BEFORE a capture on that stream: allocated inside one, the zero-fill of
+    the flag words becomes a graph node that re-zeroes the sticky error word on every replay, and both buffers land in the
+    graph's private pool.  sampler.sample_loop / bench.py warm up and capture on the SAME stream, so this never fires
+    there; a caller that captures on a stream of its own must run one eager step on it first."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise _lib.OfxError('%s of this stream would be allocated inside a hipGraph capture: run one eager step on the '
+                            'capture stream first (sampler.sample_loop does)' % what)
 
 
 def sync_error(device):
@@ -333,6 +344,14 @@ def range_words(device):
     return t
 
 
+def reset_range_words(device):
+    """Start of a sampling stage: the out-of-range count describes THIS stage only (the word is sticky, and a
+    count left by an earlier training forward / test would fail the next sample_loop and switch the process to bf16x3)."""
+    t = _RANGE.get((device.type, device.index if device.index is not None else torch.cuda.current_device()))
+    if t is not None:
+        t.zero_()
+
+
 def range_error(device, result=None):
     """{'operands_beyond_fp16': n, 'result_non_finite': bool} if operands left the fp16 range on `device` since the words
     were last cleared -- or `result` (a tensor the suspect launches produced) is non-finite: an operand beyond the range
@@ -370,6 +389,7 @@ def workspace(device, nbytes=96 << 20):
     key = (device.type, device.index, _stream_id(device))
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
+        _no_capture('the split-K / hand-off workspace')
         t = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _WS[key] = t
     return t
@@ -560,6 +580,110 @@ def graphconv(x, nbr, seg_ptr, col, pw, cin, type_frac=None, bias=None, emb=None
         # fused-op algorithmic bytes: one feature row per edge + output + weights + 8 B/edge
         nbytes = 4.0 * (E * cin + N * pw.N + k_logical * pw.N) + 8.0 * E
         prof.append((e0, e1, flops, nbytes, pw.N, ('graph', N, cin, pw.N)))
+    return out
+
+
+NARROW_IN = os.environ.get('OFX_NARROW_IN', '1') == '1'      # A/B switches of the two gather-shaped GraphConvs (csrc/ofx_narrow.hip)
+NARROW_OUT = os.environ.get('OFX_NARROW_OUT', '1') == '1'
+
+
+def narrow_in_ok(cin, cout, nt):
+    return NARROW_IN and cin <= 8 and cout in (64, 128) and 7 * (cin + nt) <= 96
+
+
+def graphconv_narrow_in(x, seg_ptr, col, weights, cin, nt, type_frac=None, bias=None, batch_id=None, out=None, stats=None):
+    """The U-Net's INPUT GraphConv (3 / 8 channels -> 64 / 128): gather + exact-fp32 FMA with the weights in registers
+    (ofx_graphconv_narrow_in).  weights: the raw nn.Parameter [7 * (cin + nt), cout]."""
+    x, ldx = _row_major(x)
+    w = weights.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    _chk(w)
+    N, cout = x.shape[0], w.shape[1]
+    assert x.shape[1] == cin and w.shape[0] == 7 * (cin + nt)
+    if out is None:
+        out = torch.empty(N, cout, dtype=torch.float32, device=x.device)
+    out2, ldc = _row_major(out)
+    assert out2 is out
+    ldt = 0
+    if nt:
+        _chk(type_frac)
+        ldt = type_frac.stride(0)
+    _chk(bias)
+    _chk(stats, torch.float64)
+    if stats is not None:
+        _chk(batch_id, torch.int32)
+    prof = GRAPHCONV_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    ws = workspace(x.device)
+    E = col.numel()
+    flops = 2.0 * N * w.shape[0] * cout
+    nbytes = 4.0 * (E * cin + N * cout + w.numel()) + 8.0 * E
+    _meta('graphconv_narrow', flops, nbytes, (N, cin, cout, 'narrow_in'))
+    call('ofx_graphconv_narrow_in', ptr(x), ldx, cin, N, ptr(seg_ptr), ptr(col), ptr(type_frac) if nt else None, ldt, nt,
+         ptr(w), cout, ptr(bias), ptr(batch_id) if stats is not None else None, ptr(out), ldc, ptr(stats), cout,
+         ptr(ws), ws.numel(), stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, flops, nbytes, cout, ('graph', N, cin, cout)))
+    return out
+
+
+class PackedNarrowOut:
+    """Wd [C, pw] of the project-then-aggregate output GraphConv (ofx_narrow_out_pack) + its MFMA pack."""
+
+    def __init__(self):
+        self.key = None
+        self.pw = PackedWeight()
+
+    def get(self, w, C, nt):
+        key = (w.data_ptr(), w._version, tuple(w.shape), C, nt)
+        if key != self.key:
+            wd = w.detach()
+            if not wd.is_contiguous():
+                wd = wd.contiguous()
+            _chk(wd)
+            cout = wd.shape[1]
+            self.width = 32 if 7 * cout <= 32 else 64
+            self.wd = torch.empty(C, self.width, dtype=torch.float32, device=w.device)
+            call('ofx_narrow_out_pack', ptr(wd), C, nt, cout, self.width, ptr(self.wd), stream())
+            self.w = wd
+            self.key = key
+        return self
+
+
+def graphconv_narrow_out(x, seg_ptr, col, pno, C, nt, type_frac=None, bias=None, out=None):
+    """The U-Net's OUTPUT GraphConv (C channels -> 3 / 8) as project-then-aggregate: one dense GEMM P = x @ Wd (x read once,
+    coalesced), then a gather of cout floats per edge (ofx_graphconv_narrow_out)."""
+    N = x.shape[0]
+    cout = pno.w.shape[1]
+    prof = GRAPHCONV_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    P = gemm(x, pno.pw.get(pno.wd, 'kn'))
+    if out is None:
+        out = torch.empty(N, cout, dtype=torch.float32, device=x.device)
+    out2, ldc = _row_major(out)
+    assert out2 is out
+    ldt = 0
+    if nt:
+        _chk(type_frac)
+        ldt = type_frac.stride(0)
+    _chk(bias)
+    E = col.numel()
+    flops = 2.0 * N * pno.w.shape[0] * cout
+    nbytes = 4.0 * (E * C + N * cout + pno.w.numel()) + 8.0 * E         # the operator's algorithmic bytes (SURVEY 8d), not this path's
+    _meta('graphconv_narrow', flops, nbytes, (N, C, cout, 'narrow_out'))
+    call('ofx_graphconv_narrow_out', ptr(P), P.stride(0), cout, N, ptr(seg_ptr), ptr(col), ptr(type_frac) if nt else None,
+         ldt, nt, ptr(pno.w), C, ptr(bias), ptr(out), ldc, stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, flops, nbytes, cout, ('graph', N, C, cout)))
     return out
 
 

@@ -112,13 +112,20 @@ class CascadeSampler:
         fp16 range; the process has been switched to bf16x3 by then).  With per-shape generators or a seed the retry
         draws the same noise; a caller that relies on the global RNG state gets a fresh draw."""
         from . import ops
+        before = ops.get_precision()
+        timings = kwargs.get('timings')
         try:
             return self._sample_once(*args, **kwargs)
         except ops.OfxRangeError:
-            if ops.get_precision() == 'fp16x3':
+            # retry only if raise_on_range_error really moved the process to another precision (it does for 'fp16x3'
+            # with AUTO_RANGE_FALLBACK; in the reduced 'fp16' mode, or with the fallback off, a second pass in the same
+            # arithmetic would fail the same way)
+            if ops.get_precision() == before:
                 raise
             import warnings
-            warnings.warn('octfusion_amd: fp16x3 range guard tripped -- sampling again in bf16x3')
+            warnings.warn('octfusion_amd: fp16x3 range guard tripped -- sampling again in %s' % ops.get_precision())
+            if timings is not None:
+                timings.clear()                      # the failed pass's phases are not part of the result
             return self._sample_once(*args, **kwargs)
 
     def _sample_once(self, batch_size, ddim_steps=200, label=None, split_small=None, noises=None, sdf_resolution=None,

@@ -83,6 +83,8 @@ def sample_loop(net, shape, batch_size, ddim_steps, unet_type, df_type, device, 
         use_graph = torch.device(device).type == 'cuda' and isinstance(net, torch.nn.Module)
     x = torch.randn(shape, device=device) if init_noise is None else init_noise.to(device).clone()
     x = x.contiguous()
+    if x.is_cuda:
+        ops.reset_range_words(x.device)
     wants_sc = getattr(net, 'wants_self_cond', True)
     x_start = None
     graphs = {}
@@ -133,7 +135,10 @@ def sample_loop(net, shape, batch_size, ddim_steps, unet_type, df_type, device, 
                 _step(*args)                           # warm-up of this regime outside the capture
             torch.cuda.current_stream().wait_stream(side)
             x.copy_(keep)
-            with torch.cuda.graph(g):
+            # capture on the warm-up stream: its flag words and workspace (ops.sync_words / ops.workspace are per stream)
+            # were allocated by the eager warm-up above, so the capture contains no allocation and no zero-fill of the
+            # sticky error word
+            with torch.cuda.graph(g, stream=side):
                 res = _step(*args)
             x.copy_(keep)
             graphs[key] = (g, c, res)

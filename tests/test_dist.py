@@ -71,7 +71,31 @@ def test_bench_spawns_its_own_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     rec = json.loads(line)
-    assert rec == {'bootstrap': 'ok', 'world': 2, 'max_rank_seen': 1.0, 'shard_of_10': [0, 2, 4, 6, 8]}
+    assert rec == {'bootstrap': 'ok', 'world': 2, 'max_rank_seen': 1.0, 'broadcast_value': 0.0, 'shard_of_10': [0, 2, 4, 6, 8],
+                   'ranks': [[0, 0, 'cpu'], [1, 1, 'cpu']], 'shapes_of_64_per_rank': [32.0, 32.0],
+                   'shard_of_64_last_rank': list(range(1, 64, 2))}
+
+
+def test_bench_bootstrap_at_world_8():
+    """the launch the driver uses for the 8-GPU line (`--gpus 8`, one rank per GPU) rendezvouses,
+    runs every collective kind of the timed path, shards 64 shapes by the reference's rule (train.py:166-185: rank r takes
+    i = r, r + 8, ...) and prints EXACTLY ONE JSON line on stdout -- over gloo on this CPU-only machine."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env['OMP_NUM_THREADS'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--bootstrap-only'],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['world'] == 8 and rec['max_rank_seen'] == 7.0 and rec['broadcast_value'] == 0.0
+    assert rec['ranks'] == [[i, i, 'cpu'] for i in range(8)]
+    assert rec['shapes_of_64_per_rank'] == [8.0] * 8
+    assert rec['shard_of_64_last_rank'] == [7, 15, 23, 31, 39, 47, 55, 63]
 
 
 def test_bench_rank_command_is_the_documented_one():
@@ -117,6 +141,38 @@ def _grad_worker(rank, world, port, out):
     if rank == 0:
         torch.save({'ok': ok, 'nbytes': nbytes, 'numel': sum(v.numel() for v in grads.values())}, out)
     dist.destroy_process_group()
+
+
+def _diverging_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from octfusion_amd import dist as D
+    D.init(backend='gloo')
+    grads = {'a.weight': torch.ones(9, 4) * (rank + 1), 'b.bias': torch.ones(4)}
+    D.all_reduce_mean_(grads)                                        # step 1: the same set everywhere
+    ok1 = bool(torch.allclose(grads['a.weight'], torch.full((9, 4), 1.5)))
+    if rank == 1:
+        del grads['b.bias']                                          # step 2: rank 1 lost a gradient
+    raised = False
+    try:
+        D.all_reduce_mean_(grads)
+    except RuntimeError as e:
+        raised = 'different gradient sets' in str(e)
+    flags = [None] * world
+    dist.all_gather_object(flags, (ok1, raised))
+    if rank == 0:
+        torch.save(flags, out)
+    dist.destroy_process_group()
+
+
+def test_gradient_set_divergence_after_step_one_raises_on_every_rank(tmp_path):
+    """the gradient-set check is a collective EVERY rank issues on EVERY call.  A set that diverges
+    after a verified first step (a parameter without gradient on one rank) must raise on both ranks -- not hang, not
+    reduce mismatched buckets -- which a rank-local 'already verified' skip could not guarantee."""
+    out = str(tmp_path / 'd.pt')
+    mp.spawn(_diverging_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert torch.load(out) == [(True, True), (True, True)]
 
 
 def test_gradient_all_reduce_world2(tmp_path):

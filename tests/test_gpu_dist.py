@@ -37,7 +37,7 @@ def test_rccl_world1_runs_every_collective_on_the_device():
         assert dist.all_reduce_mean_(g, bucket_bytes=1 << 12) == 4 * (257 * 33 + 5)       # two buckets
         for k in g:
             assert torch.equal(g[k], want[k])
-        assert dist.all_reduce_mean_(g) == 4 * (257 * 33 + 5)                            # verified set: no second check
+        assert dist.all_reduce_mean_(g) == 4 * (257 * 33 + 5)                            # the set check runs again (every call, every rank)
         opt = training.AdamW({'w': torch.nn.Parameter(torch.randn(64, 8, device=dev()))})
         assert opt.sync_() == 4 * 64 * 8 * 3                                             # parameters + two moments
         dist.barrier()

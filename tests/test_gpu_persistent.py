@@ -14,11 +14,49 @@ What is specific to this launch shape and therefore checked here:
 import pytest
 import torch
 
+import functools
+
 import common as C
-from test_gpu_fullwidth import dev, errors, report, shell6
+import oracle_cache as OC
+from test_gpu_fullwidth import dev, errors, report, shell6, shell6_gpu, shell6_oracle
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
+
+
+def _gn_conv_case(prefix, B, d, cin, cout):
+    """fp64 oracle of SiLU(GroupNorm(x)) -> GraphConv + emb[batch] + res on the jittered shell-6 batch of B shapes
+    (modules.py:194-220, 291-314) -- CPU only."""
+    from oracle import modules as OM
+    _, o_doc = shell6_oracle(B)
+    N = int(o_doc.graph[d]['keyd'].shape[0])
+    sd = C.fill_state_dict([('c.weights', (7 * (cin + d - 1), cout)), ('g.weights', (1, cin)), ('g.bias', (1, cin))])
+    x = C.rand_input('%s_x_%d_%d' % (prefix, d, cin), N, cin)
+    emb = C.rand_input('%s_e_%d' % (prefix, cout), B, cout)
+    res = C.rand_input('%s_r_%d_%d' % (prefix, d, cout), N, cout)
+    h_ref = OM.silu(OM.dual_octree_group_norm(x.double(), o_doc, d, sd['g.weights'].double(), sd['g.bias'].double()))
+    return {'ref': OM.graph_conv(h_ref, o_doc, d, sd['c.weights'].double(), None, d - 1) + emb.double()[o_doc.batch_id(d)]
+            + res.double()}
+
+
+def _conv_case(B, d, cin, cout):
+    from oracle import modules as OM
+    _, o_doc = shell6_oracle(B)
+    N = int(o_doc.graph[d]['keyd'].shape[0])
+    w = C.fill_state_dict([('weights', (7 * (cin + d - 1), cout))])['weights']
+    x = C.rand_input('pk1_shell6_b1_%d_%d' % (d, cin), N, cin)
+    return {'ref': OM.graph_conv(x.double(), o_doc, d, w.double(), None, d - 1)}
+
+
+PK2_SHAPES = [(6, 128, 128), (5, 256, 256), (6, 64, 64), (6, 384, 128), (4, 128, 128), (5, 128, 320)]
+PK8_SHAPES = [(6, 128, 128), (5, 256, 512)]
+PK1_SHAPES = [(6, 128, 128), (5, 256, 256), (6, 32, 128)]
+for _s in PK2_SHAPES:
+    OC.register('pk_%d_%d_%d' % _s, functools.partial(_gn_conv_case, 'pk', 2, *_s))
+for _s in PK8_SHAPES:
+    OC.register('pk8_%d_%d_%d' % _s, functools.partial(_gn_conv_case, 'pk8', 8, *_s))
+for _s in PK1_SHAPES:
+    OC.register('pk1_%d_%d_%d' % _s, functools.partial(_conv_case, 1, *_s))
 
 
 def _run(conv, gn, x, doc, d, mode, emb, res, stats_n):
@@ -38,18 +76,16 @@ def _run(conv, gn, x, doc, d, mode, emb, res, stats_n):
 @pytest.mark.parametrize('prec', ['fp16x3', 'bf16x3', 'fp16'])
 def test_persistent_vs_tile_launch_and_oracle(prec):
     from octfusion_amd import _lib, modules as M, ops
-    from oracle import modules as OM
     mode = {'fp16x3': 3, 'bf16x3': 2, 'fp16': 1}[prec]
     tol = {'fp16x3': 2e-5, 'bf16x3': 2e-4, 'fp16': 5e-3}[prec]
     B = 2
-    oc, doc, o_oc, o_doc = shell6(B)
+    oc, doc = shell6_gpu(B)
     saved = ops.get_precision()
     ops.set_precision(prec)
     try:
         # (depth, cin, cout): 128-column tiles with one / two column tiles, 64-column tiles, a wide-K layer, a depth
         # with fewer 256-row tiles than CUs (several blocks share a tile)
-        shapes = [(6, 128, 128), (5, 256, 256), (6, 64, 64), (6, 384, 128), (4, 128, 128), (5, 128, 320)]
-        for d, cin, cout in shapes:
+        for d, cin, cout in PK2_SHAPES:
             if mode == 1 and cin % 64:
                 continue
             nt = d - 1
@@ -64,8 +100,7 @@ def test_persistent_vs_tile_launch_and_oracle(prec):
             x = C.rand_input('pk_x_%d_%d' % (d, cin), N, cin)
             emb = C.rand_input('pk_e_%d' % cout, B, cout)
             res = C.rand_input('pk_r_%d_%d' % (d, cout), N, cout)
-            h_ref = OM.silu(OM.dual_octree_group_norm(x.double(), o_doc, d, sd['g.weights'].double(), sd['g.bias'].double()))
-            ref = OM.graph_conv(h_ref, o_doc, d, sd['c.weights'].double(), None, nt) + emb.double()[o_doc.batch_id(d)] + res.double()
+            ref = OC.get('pk_%d_%d_%d' % (d, cin, cout))['ref']
             xg, eg, rg = x.to(dev()), emb.to(dev()), res.to(dev())
             sn = B * cout * 2
             _lib.call('ofx_set_gconv_persistent', 0)
@@ -108,8 +143,8 @@ def test_persistent_single_shape_and_ragged():
     from octfusion_amd.octree import split2octree_small
     from oracle import dual_octree as OD, modules as OM, sampler as OS
     cases = []
-    oc, doc, o_oc, o_doc = shell6(1)
-    cases.append(('shell6_b1', doc, o_doc, 1, [(6, 128, 128), (5, 256, 256), (6, 32, 128)]))
+    oc, doc = shell6_gpu(1)
+    cases.append(('shell6_b1', doc, None, 1, PK1_SHAPES))
     split = C.random_split_small(3, 3, 77, p=0.45)
     doc_r = DualOctree(split2octree_small(split.to(dev()), 5, 3))
     o_r = OD.OracleDualOctree(OS.split2octree_small(split, 5, 3))
@@ -126,7 +161,8 @@ def test_persistent_single_shape_and_ragged():
                 conv = conv.to(dev())
                 N = dc.csr(d)[2]
                 x = C.rand_input('pk1_%s_%d_%d' % (name, d, cin), N, cin)
-                ref = OM.graph_conv(x.double(), oc_, d, sd['weights'].double(), None, nt)
+                ref = (OC.get('pk1_%d_%d_%d' % (d, cin, cout))['ref'] if oc_ is None else
+                       OM.graph_conv(x.double(), oc_, d, sd['weights'].double(), None, nt))
                 for tile in (2, 4):
                     _lib.call('ofx_set_gconv2_tile', tile)
                     saved = ops.PLANES_MIN_TILES
@@ -150,11 +186,10 @@ def test_whole_tile_rounds_plus_region_at_bench_size():
     one-tile-per-block launches of the same layer agree, and the default one matches the fp64 oracle.  One layer with a
     single column tile (halo sharing only) and one with four (the column tiles of a row tile run on one XCD together)."""
     from octfusion_amd import _lib, modules as M, ops
-    from oracle import modules as OM
     B = 8
-    oc, doc, o_oc, o_doc = shell6(B)
+    oc, doc = shell6_gpu(B)
     try:
-        for d, cin, cout in [(6, 128, 128), (5, 256, 512)]:
+        for d, cin, cout in PK8_SHAPES:
             nt = d - 1
             conv = M.GraphConv(cin, cout, 7, 7, nt)
             gn = M.DualOctreeGroupNorm(cin)
@@ -167,8 +202,7 @@ def test_whole_tile_rounds_plus_region_at_bench_size():
             x = C.rand_input('pk8_x_%d_%d' % (d, cin), N, cin)
             emb = C.rand_input('pk8_e_%d' % cout, B, cout)
             res = C.rand_input('pk8_r_%d_%d' % (d, cout), N, cout)
-            h_ref = OM.silu(OM.dual_octree_group_norm(x.double(), o_doc, d, sd['g.weights'].double(), sd['g.bias'].double()))
-            ref = OM.graph_conv(h_ref, o_doc, d, sd['c.weights'].double(), None, nt) + emb.double()[o_doc.batch_id(d)] + res.double()
+            ref = OC.get('pk8_%d_%d_%d' % (d, cin, cout))['ref']
             xg, eg, rg = x.to(dev()), emb.to(dev()), res.to(dev())
             ys = {}
             for pers in (0, 1, 2):

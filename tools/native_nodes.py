@@ -1,0 +1,137 @@
+"""Which nodes of a captured denoising step are NOT libofx kernels, and which Python line launches each (VERDICT r04
+weak #3: torch-native copies / fills / cat kernels inside the step).
+
+    python tools/native_nodes.py [--workload hr] [--batch 8] --out gpurun_out/native_nodes_hr.json
+
+Two views of the same step:
+  * `replay`: kernel / memcpy / memset names of ONE hipGraph replay of the captured step (torch.profiler device events),
+    split into libofx kernels and everything else -- the node count the step really has;
+  * `eager_sources`: one eager step under torch.profiler with Python stacks: every ATen operator that launched device
+    work (aten::copy_, aten::zero_, aten::cat, ...) with the innermost repo frame that called it.
+"""
+import argparse
+import collections
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+import bench
+from octfusion_amd import _lib, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OFX_KERNELS = None
+
+
+def ofx_kernel_names():
+    """Kernel symbols of libofx.so (demangled prefixes), so that a device event can be attributed to the library."""
+    global OFX_KERNELS
+    if OFX_KERNELS is None:
+        import re
+        import subprocess
+        out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-nm', '-C', '--defined-only', _lib.LIB_PATH], capture_output=True,
+                             text=True).stdout
+        names = set()
+        for line in out.splitlines():
+            m = re.search(r'__device_stub__(\w+)', line)
+            if m:
+                names.add(m.group(1))
+        OFX_KERNELS = names
+    return OFX_KERNELS
+
+
+def is_ofx(name):
+    base = name.replace('void ', '').split('<')[0].split('(')[0].strip()
+    return base in ofx_kernel_names()
+
+
+def device_events(prof):
+    out = []
+    for e in prof.events():
+        if str(getattr(e, 'device_type', '')).endswith('CUDA') and e.name:
+            out.append((e.name, e.device_time_total if hasattr(e, 'device_time_total') else e.cuda_time_total))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--workload', default='hr')
+    ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--out', default=None)
+    a = ap.parse_args()
+    torch.set_grad_enabled(False)
+    dev = torch.device('cuda:0')
+    _lib.require_device()
+    ops.set_precision('fp16x3')
+    w = bench.WORKLOADS[a.workload]
+    wl = bench.Workload(a.workload, a.batch or w['batch'], dev, 0)
+    wl.run(0, 3)
+    torch.cuda.synchronize()
+
+    # ---- eager step with stacks
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        wl.run(3, 1)
+        torch.cuda.synchronize()
+    src = collections.Counter()
+    for e in prof.events():
+        if not e.name.startswith('aten::') or not getattr(e, 'kernels', None):
+            continue
+        if e.cpu_parent is not None and e.cpu_parent.name.startswith('aten::') and getattr(e.cpu_parent, 'kernels', None):
+            continue                                    # count the outermost operator only
+        frame = next((f for f in (e.stack or []) if ROOT in f and 'tools/native_nodes' not in f), '?')
+        frame = frame.replace(ROOT + '/', '')
+        src[(e.name, frame, tuple(sorted(set(k.name.split('<')[0][:60] for k in e.kernels))))] += 1
+    eager_sources = [{'op': k[0], 'at': k[1], 'kernels': list(k[2]), 'count': v} for k, v in src.most_common()]
+
+    # ---- one graph replay (capture exactly like bench.py / sampler.sample_loop)
+    cond_s = wl.cond[0].expand(wl.batch).contiguous().clone()
+    coef_s = wl.coef[0].clone()
+    noise_s = torch.randn_like(wl.x) if wl.df == 'x0' else None
+    self_s = torch.zeros_like(wl.x) if wl.stage == 'lr' else None
+
+    def gstep():
+        return wl.sampler._step(wl.net, wl.x, cond_s, wl.stage, wl.df, wl.doc, wl.nested, wl.label, self_s, coef_s, noise_s,
+                                False, None)
+    side = ops.side_stream(dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        gstep()
+        gstep()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        gstep()
+    g.replay()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof2:
+        g.replay()
+        torch.cuda.synchronize()
+    ev = device_events(prof2)
+    names = collections.Counter(n for n, _ in ev)
+    tus = collections.Counter()
+    for n, t in ev:
+        tus[n] += t
+    ofx = {n: c for n, c in names.items() if is_ofx(n)}
+    other = {n: c for n, c in names.items() if not is_ofx(n)}
+    res = {'workload': a.workload, 'batch': wl.batch,
+           'replay': {'nodes': sum(names.values()), 'libofx_kernel_nodes': sum(ofx.values()), 'other_nodes': sum(other.values()),
+                      'other_us': sum(tus[n] for n in other),
+                      'other': sorted(([n[:100], c, round(tus[n], 1)] for n, c in other.items()), key=lambda r: -r[1]),
+                      'libofx': sorted(([n[:80], c, round(tus[n], 1)] for n, c in ofx.items()), key=lambda r: -r[2])},
+           'eager_sources': eager_sources}
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        json.dump(res, open(a.out, 'w'), indent=1)
+    print(json.dumps({'workload': a.workload, 'nodes': res['replay']['nodes'], 'libofx': res['replay']['libofx_kernel_nodes'],
+                      'other_nodes': res['replay']['other_nodes'], 'other_us': res['replay']['other_us']}))
+    for r in res['replay']['other']:
+        print('  other', r)
+    for r in eager_sources[:40]:
+        print('  src', r['count'], r['op'], r['at'], r['kernels'])
+
+
+if __name__ == '__main__':
+    main()

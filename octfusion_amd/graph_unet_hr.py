@@ -149,18 +149,31 @@ class UNet3DModel(nn.Module):
     def _forward(self, x, doctree, unet_lr, timesteps, label, context, as_middle):
         assert (label is not None) == (self.num_classes is not None), \
             'must specify y if and only if the model is class-conditional'
-        t_emb = ops.timestep_embedding(timesteps.float(), self.model_channels)
-        # time_embed = Linear -> SiLU -> Linear (+ label embedding), then every res-block applies SiLU to it
-        # (modules.py:754): the activations ride in the few-row linear launches
-        lab = None
-        if self.num_classes is not None:
-            assert label.shape == (doctree.batch_size,)
-            lab = self.label_emb(label)
-        emb_act = self.time_embed[2](self.time_embed[0](t_emb, act_out='silu'), res=lab, act_out='silu')
+        timesteps = timesteps.float()
         emb = None                              # (the blocks get SiLU(emb) and their own projection of it)
-        # every res-block applies its own Linear(ted -> Cout) to the same SiLU(emb) (modules.py:754): one GEMM
-        # against the row-concatenated weights instead of one launch per block
-        emb_outs = self._all_emb_outs(emb_act)
+
+        def embed():
+            t_emb = ops.timestep_embedding(timesteps, self.model_channels)
+            # time_embed = Linear -> SiLU -> Linear (+ label embedding), then every res-block applies SiLU to it
+            # (modules.py:754): the activations ride in the few-row linear launches
+            lab = None
+            if self.num_classes is not None:
+                assert label.shape == (doctree.batch_size,)
+                lab = self.label_emb(label)
+            e_act = self.time_embed[2](self.time_embed[0](t_emb, act_out='silu'), res=lab, act_out='silu')
+            # every res-block applies its own Linear(ted -> Cout) to the same SiLU(emb) (modules.py:754): one GEMM
+            # against the row-concatenated weights instead of one launch per block
+            return e_act, self._all_emb_outs(e_act)
+        # the embedding chains of this net and of the nested one depend on the timesteps only: parallel branches beside
+        # the input convolution / the encoder (ops.fork_stream), joined where the first res-block needs them
+        emb_main, emb_fork = ops.fork_stream(x.device)
+        if emb_fork is not None:
+            with torch.cuda.stream(emb_fork):
+                emb_act, emb_outs = embed()
+            if unet_lr is not None and hasattr(unet_lr, 'precompute_embeddings'):
+                unet_lr.precompute_embeddings(timesteps, label, doctree.batch_size)
+        else:
+            emb_act, emb_outs = embed()
 
         # Zero-copy skip concatenation: the decoder block that consumes skip tensor i reads ONE buffer
         # [N, C_h + C_skip]; the encoder module that produces the skip writes straight into its right
@@ -184,6 +197,8 @@ class UNet3DModel(nn.Module):
         else:
             h = self.input_blocks[0](x, doctree, d, out=skip_slot(0))
             hs = [h]
+        if emb_fork is not None:
+            emb_main.wait_stream(emb_fork)
         for k, ((kind, dd, _), module) in enumerate(zip(self._enc, self.input_blocks[1:])):
             slot = skip_slot(k + 1)
             if kind == 'res':

@@ -250,12 +250,22 @@ class ResnetBlock(nn.Module):
         if gs is None:
             rows, gs, back = _dense_io(x)
             return back(self.forward(rows, ops.act(emb_act.float().contiguous(), 'silu'), gs), gs.depth)
+        # the 1x1 residual convolution only needs x: a parallel branch (ops.fork_stream), joined before conv2 adds it
+        skip, main, fork = x, None, None
+        if not isinstance(self.res_conv, nn.Identity):
+            main, fork = ops.fork_stream(x.device)
+            if fork is not None:
+                with torch.cuda.stream(fork):
+                    skip = self.res_conv(x)
+            else:
+                skip = self.res_conv(x)
         h = self.block1[0](x, gs, act='silu')
         if t is None:
             t = self.time_mlp[1](emb_act)                   # [B, dim_out]
         h = self.block1[2](h, gs, emb=t)                    # conv + bias + t[batch] fused
         h = self.block2[0](h, gs, act='silu', out=h)
-        skip = x if isinstance(self.res_conv, nn.Identity) else self.res_conv(x)
+        if fork is not None:
+            main.wait_stream(fork)
         return self.block2[3](h, gs, res=skip, out=out)
 
 
@@ -402,12 +412,32 @@ class UNet3DModel(nn.Module):
         with ops.policy_scope('dense_net'):
             return self._forward_rows(x, batch_size, timesteps, label, as_middle)
 
+    @torch.no_grad()
+    def precompute_embeddings(self, timesteps, label, batch_size):
+        """The embedding chain (4 launches that depend on the timesteps only) on the fork stream; the nesting sparse net
+        calls this at the START of its own forward, so that the chain runs beside its encoder instead of in the middle of
+        the step.  Consumed (and joined) by the next _forward_rows with the same timesteps tensor."""
+        main, fork = ops.fork_stream(timesteps.device)
+        if fork is None:
+            return
+        with torch.cuda.stream(fork):
+            emb_act = self._embed(timesteps, label, batch_size)
+            tms = self._all_time_mlps(emb_act)
+        self._pre = (timesteps, label, batch_size, emb_act, tms, main, fork)
+
     def _forward_rows(self, x, batch_size, timesteps, label, as_middle):
         gs = GridState(batch_size, self.full_depth, x.device)
         if not as_middle:
             x = self.input_emb(x, gs)
-        emb_act = self._embed(timesteps, label, batch_size)
-        tms = self._all_time_mlps(emb_act)
+        pre, self._pre = getattr(self, '_pre', None), None
+        if pre is not None and pre[0] is timesteps and pre[1] is label and pre[2] == batch_size:
+            emb_act, tms = pre[3], pre[4]
+            pre[5].wait_stream(pre[6])
+        else:
+            if pre is not None:
+                pre[5].wait_stream(pre[6])              # (an unused precompute: still joined, never left dangling)
+            emb_act = self._embed(timesteps, label, batch_size)
+            tms = self._all_time_mlps(emb_act)
 
         # Zero-copy skip concatenation (as the sparse net does): the decoder level that consumes the skip tensor of
         # encoder level i reads ONE buffer [rows_i, C_x + C_skip]; the module that produces the skip writes its right

@@ -274,6 +274,30 @@ def side_stream(device):
     return s
 
 
+# OFX_FORK=1 (default): work that does not depend on the activation chain -- the embedding MLPs of both nets, the 1x1
+# residual convolutions of the dense net's ResnetBlocks -- is issued on a second stream and joined where its result
+# is consumed.  Inside a captured step these become parallel branches of the hipGraph: ~19 launches of 5-15 us leave
+# the step's critical path.  (The sparse net's 1x1 skip convolutions stay on the main stream: next to a persistent
+# GraphConv launch that owns every CU they were measured slower, OFX_SIDE_STREAM above.)
+FORK = os.environ.get('OFX_FORK', '1') == '1'
+_FORK = {}
+
+
+def fork_stream(device):
+    """(main, fork) streams of `device` when forking is on and the tensor lives on a HIP device, else (None, None).  The
+    fork stream is NOT sampler.sample_loop's warm-up / capture stream (side_stream): a fork happens inside a step."""
+    if not FORK or device.type != 'cuda':
+        return None, None
+    s = _FORK.get(device.index)
+    if s is None:
+        s = _FORK[device.index] = torch.cuda.Stream(device)
+    main = torch.cuda.current_stream(device)
+    if main.cuda_stream == s.cuda_stream:
+        return None, None
+    s.wait_stream(main)
+    return main, s
+
+
 _SYNC = {}
 SYNC_WORDS = 4096
 

@@ -1,0 +1,105 @@
+"""The two gather-shaped GraphConvs of a U-Net (csrc/ofx_narrow.hip) against the oracle in float64
+(reference models/networks/modules.py:194-220; call sites graph_unet_hr.py:116 and :205-209).
+
+  * input convolution (3 / 8 channels -> 64 / 128): exact fp32 FMA -> 2e-6 rel-to-max; fused GroupNorm statistics incl.
+    blocks that hold a batch boundary (ragged batch: boundaries fall inside 64-row blocks), bias, output written into a
+    column slice of a wider buffer (the zero-copy skip concatenation), nt = 0;
+  * output convolution (64 / 128 channels -> 3 / 8) as project-then-aggregate: the dense projection runs in the default
+    contraction precision (fp16x3) -> 2e-5; multi-neighbour segments, empty segments, bias;
+  * both through `modules.GraphConv.forward`, with the switches off as the A/B (the contraction kernels they replace).
+"""
+import pytest
+import torch
+
+import common as C
+from test_gpu_fullwidth import dev, errors
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _trees():
+    from octfusion_amd.dual_octree import DualOctree
+    from octfusion_amd.octree import split2octree_small
+    from oracle import dual_octree as OD, sampler as OS
+    split = C.random_split_small(5, 3, 91, p=0.45)
+    split[2] = -1.0                                   # an element with nothing below the full layer
+    doc = DualOctree(split2octree_small(split.to(dev()), 5, 3))
+    o_doc = OD.OracleDualOctree(OS.split2octree_small(split, 5, 3))
+    o_doc.post_processing_for_docnn()
+    return doc, o_doc
+
+
+@pytest.mark.parametrize('cin,cout,d,nt,bias', [(3, 128, 5, 4, False), (8, 128, 5, 4, True), (3, 64, 4, 3, True),
+                                                (4, 128, 5, 0, False), (8, 64, 5, 4, False)])
+def test_narrow_input_conv(cin, cout, d, nt, bias):
+    from octfusion_amd import modules as M, ops
+    from oracle import modules as OM
+    doc, o_doc = _trees()
+    N = doc.csr(d)[2]
+    B = doc.batch_size
+    conv = M.GraphConv(cin, cout, 7, 7, nt, use_bias=bias)
+    sd = C.fill_state_dict([(k, tuple(v.shape)) for k, v in conv.state_dict().items()])
+    conv.load_state_dict(sd)
+    conv = conv.to(dev())
+    x = C.rand_input('nin_%d_%d_%d' % (cin, cout, d), N, cin)
+    ref = OM.graph_conv(x.double(), o_doc, d, sd['weights'].double(), sd['bias'].double() if bias else None, nt)
+    assert ops.narrow_in_ok(cin, cout, nt if nt > 1 else 0)
+    wide = torch.full((N, cout + 64), 7.0, device=dev())
+    with ops.stats_scope(dev()):
+        y = conv(x.to(dev()), doc, d, out=wide[:, 64:])
+        st = ops.get_stats(y)
+        assert y.data_ptr() == wide[:, 64:].data_ptr() and bool((wide[:, :64] == 7.0).all())
+        e = errors(y, ref)
+        assert e['rel_to_max'] < 2e-6, e
+        if N * cout >= (1 << 14):
+            assert st is not None
+            bid = doc.batch_id32(d).long()
+            want = torch.zeros(B, cout, 2, dtype=torch.float64, device=dev())
+            want[:, :, 0].index_add_(0, bid, y.double())
+            want[:, :, 1].index_add_(0, bid, y.double() ** 2)
+            assert float((st.view(B, cout, 2) - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    # A/B: the contraction path it replaces gives the same operator
+    ops.NARROW_IN = False
+    try:
+        y_old = conv(x.to(dev()), doc, d)
+    finally:
+        ops.NARROW_IN = True
+    assert errors(y_old, ref)['rel_to_max'] < 2e-4
+
+
+@pytest.mark.parametrize('cin,cout,d,nt,bias', [(128, 3, 5, 4, False), (64, 3, 5, 4, True), (128, 8, 5, 4, True),
+                                                (64, 4, 4, 0, False)])
+def test_narrow_output_conv(cin, cout, d, nt, bias):
+    from octfusion_amd import modules as M, ops
+    from oracle import modules as OM
+    doc, o_doc = _trees()
+    N = doc.csr(d)[2]
+    conv = M.GraphConv(cin, cout, 7, 7, nt, use_bias=bias)
+    conv.emit_stats = False
+    sd = C.fill_state_dict([(k, tuple(v.shape)) for k, v in conv.state_dict().items()])
+    conv.load_state_dict(sd)
+    conv = conv.to(dev())
+    x = C.rand_input('nout_%d_%d_%d' % (cin, cout, d), N, cin)
+    ref = OM.graph_conv(x.double(), o_doc, d, sd['weights'].double(), sd['bias'].double() if bias else None, nt)
+    assert N >= 4096, N
+    y = conv(x.to(dev()), doc, d)
+    e = errors(y, ref)
+    assert e['rel_to_max'] < 2e-5, e
+    ops.NARROW_OUT = False
+    try:
+        y_old = conv(x.to(dev()), doc, d)
+    finally:
+        ops.NARROW_OUT = True
+    assert errors(y_old, ref)['rel_to_max'] < 2e-4
+    # the aggregation alone, exact: P computed in float64 on the host
+    pno = conv._pno.get(conv.weights, cin, nt if nt > 1 else 0)
+    P = (x.double() @ pno.wd.double().cpu()).float().to(dev())
+    seg_ptr, col, _, _ = doc.csr(d)
+    ntc = nt if nt > 1 else 0
+    from octfusion_amd._lib import call, ptr, stream
+    out = torch.empty(N, cout, device=dev())
+    tf = doc.type_frac(d, ntc) if ntc else None
+    call('ofx_graphconv_narrow_out', ptr(P), P.stride(0), cout, N, ptr(seg_ptr), ptr(col), ptr(tf), tf.stride(0) if ntc else 0,
+         ntc, ptr(pno.w), cin, ptr(conv.bias) if bias else None, ptr(out), cout, stream())
+    assert errors(out, ref)['rel_to_max'] < 2e-6

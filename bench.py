@@ -411,7 +411,7 @@ def gather_microbench(doc, dev, C=128, iters=20):
 
 
 KERNEL_SOURCES = ('ofx_gemm3.hip', 'ofx_planes.h', 'ofx_gemm2.hip', 'ofx_gemm.hip', 'ofx_gemm_common.h')
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r04', 'pmc_traffic.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r05', 'pmc_traffic.json')
 
 
 def kernel_source_hash():
@@ -481,7 +481,7 @@ def tail_summary(tail, steps, peak_tf, step_ms):
                             'GBps': v[3] * v[0] / (v[1] * 1e-3) / 1e9 if v[1] else None} for k, v in top],
             'note': 'HIP events around every libofx entry-point call of the eager re-run (events between calls add '
                     'host gaps: "unattributed" = eager step time minus the brackets = torch-native copies / fills + '
-                    'gaps); kernel-symbol view: profiles/r04/*kernel_stats.csv'}
+                    'gaps); kernel-symbol view: profiles/r05/bench_r05_<workload>_kernel_stats.csv'}
 
 
 def per_layer(prof):
@@ -706,7 +706,7 @@ def main():
                          'frac': dom['hbm_frac'] if bound == 'hbm' else dom['mfma_frac'],
                          'traffic': None})
             roof.update(dom)
-            tpath = PMC_FILE
+            tpath = PMC_FILE.replace('.json', '_feature.json') if args.workload == 'feature' else PMC_FILE
             if dom_is_planes and os.path.exists(tpath):       # (the counters are the planes GraphConv's: nothing to say about the dense lr stage)
                 try:
                     pj = json.load(open(tpath))
@@ -714,7 +714,7 @@ def main():
                     kernels = [L_.get('kernel', '') for L_ in pj.get('layers', [])]
                     if not kernels or not all(want_k and want_k in k_ for k_ in kernels):
                         # counters taken on another instantiation than the one this run timed say nothing about it
-                        roof['traffic_note'] = ('profiles/r04/pmc_traffic.json holds counters of %s, this run timed %s...>: '
+                        roof['traffic_note'] = ('profiles/r05/pmc_traffic.json holds counters of %s, this run timed %s...>: '
                                                 'not reported' % (sorted(set(kernels)), want_k))
                     elif pj.get('kernel_source_sha16') == kernel_source_hash():
                         # counters exist for four probe layers (tools/pmc_probe2.py); `traffic` is the HBM byte count
@@ -722,14 +722,18 @@ def main():
                         roof['traffic'] = pj.get('hbm_bytes_per_launch')
                         roof['traffic_layer'] = pj.get('hbm_bytes_per_launch_layer')
                         L0 = pj['layers'][0]
-                        roof['traffic_layer_algorithmic_bytes'] = 4.0 * (1629600 * 128 + 217008 * 128 + 931 * 128) + 8.0 * 1629600
+                        if args.workload == 'feature':       # depth-8 64 -> 64 layer of the shell-8 x 8 tree
+                            n8, e8 = wl.doc.csr(8)[2], wl.doc.csr(8)[3]
+                            roof['traffic_layer_algorithmic_bytes'] = 4.0 * (e8 * 64 + n8 * 64 + 7 * 71 * 64) + 8.0 * e8
+                        else:                                # depth-6 128 -> 128 layer of the shell-6 x 8 tree
+                            roof['traffic_layer_algorithmic_bytes'] = 4.0 * (1629600 * 128 + 217008 * 128 + 931 * 128) + 8.0 * 1629600
                         roof['traffic_per_layer'] = [{'layer': L_['layer'], 'kernel': L_['kernel'], 'hbm_bytes': L_['hbm_bytes_per_launch'],
                                                       'mfma_busy_of_clocked_cycles': L_['mfma_busy_frac_of_clocked_simd_cycles'],
                                                       'clock_ghz': L_['gpu_clock_ghz_under_kernel']} for L_ in pj['layers']]
                         roof['traffic_source'] = pj.get('source')
                         roof['mfma_pmc'] = pj.get('mfma')
                     else:
-                        roof['traffic_note'] = ('profiles/r04/pmc_traffic.json was measured on kernel sources %s, this '
+                        roof['traffic_note'] = ('profiles/r05/pmc_traffic.json was measured on kernel sources %s, this '
                                                 'build is %s: not reported' % (pj.get('kernel_source_sha16'), kernel_source_hash()))
                 except Exception as e:      # noqa: BLE001
                     roof['traffic_note'] = 'pmc_traffic.json unreadable: %s' % e

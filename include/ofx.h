@@ -381,23 +381,27 @@ int ofx_graphconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_nodes,
 /* The two GraphConvs of a diffusion U-Net that are gathers, not contractions (csrc/ofx_narrow.hip), same operator
  * (modules.py:194-220), raw nn.Parameter weights W [7 * (cin + nt), cout] row-major (no packing):
  *  ofx_graphconv_narrow_in: the INPUT convolution (graph_unet_hr.py:116), cin <= 8 channels -> cout in {64, 128},
- *      7 * (cin + nt) <= 96.  col_data of a 64-row block in LDS, a lane owns 1-2 output columns with its weights in
- *      registers, exact fp32 FMA; `stats` as in ofx_graphconv_fwd (ws >= ceil(n / 64) * cout * 8 bytes of partials).
- *      type_frac = the fp32 slab of ofx_graph_type_frac ([n, ldt], entry dir * nt + t), NULL when nt == 0.
+ *      7 * (cin + nt) <= 96, nt <= 8.  col_data of a 64-row block in LDS (node-type fractions counted from node_type
+ *      [n] uint8, the per-node type of ofx_graph_nodes, while walking the neighbours), a lane owns 1-2 output columns
+ *      with its weights in registers, exact fp32 FMA; `stats` as in ofx_graphconv_fwd (ws >= ceil(n / 64) * cout * 8
+ *      bytes of partials).
  *  ofx_graphconv_narrow_out: the OUTPUT convolution (graph_unet_hr.py:205-209), C channels -> cout <= 8, as
  *      project-then-aggregate (scatter_mean and the weight product commute): the caller first computes the dense
  *      P = y @ Wd with Wd = ofx_narrow_out_pack(W) ([C, pw], Wd[c, dir * cout + o] = W[dir * (C + nt) + c, o], pw >= 7 cout
  *      zero-padded: 32 or 64 so that a row of P is whole 128-B lines), then this call gathers cout floats per edge:
- *      out[r, o] = sum_dir mean_{e in seg(r, dir)} P[col[e], dir * cout + o] + sum_{dir, t} type_frac[r, dir * nt + t] *
- *      W[dir * (C + nt) + C + t, o] + bias[o]. */
+ *      out[r, o] = sum_dir mean_{e in seg(r, dir)} P[col[e], dir * cout + o] + type_term[r, o], where
+ *      type_term [n, cout] = ofx_narrow_out_type_term(...) = bias[o] + sum_{dir, t} type_frac[r, dir * nt + t] *
+ *      W[dir * (C + nt) + C + t, o] is constant per (graph depth, weights) -- computed once per doctree, NULL = zero. */
 int ofx_graphconv_narrow_in(const float* x, int64_t ldx, int cin, int64_t n_nodes, const int32_t* seg_ptr,
-                            const int32_t* col, const float* type_frac, int64_t ldt, int nt, const float* W, int cout,
+                            const int32_t* col, const uint8_t* node_type, int nt, const float* W, int cout,
                             const float* bias, const int32_t* batch_id, float* out, int64_t ldc,
                             double* stats /* optional */, int64_t stats_ld, void* ws, size_t ws_bytes, void* stream);
 int ofx_narrow_out_pack(const float* W, int C, int nt, int cout, int pw, float* Wd, void* stream);
+int ofx_narrow_out_type_term(const float* type_frac, int64_t ldt, int nt, int64_t n_nodes, const float* W, int C,
+                             int cout, const float* bias, float* type_term, void* stream);
 int ofx_graphconv_narrow_out(const float* P, int64_t ldp, int cout, int64_t n_nodes, const int32_t* seg_ptr,
-                             const int32_t* col, const float* type_frac, int64_t ldt, int nt, const float* W, int C,
-                             const float* bias, float* out, int64_t ldc, void* stream);
+                             const int32_t* col, const float* type_term /* optional */, float* out, int64_t ldc,
+                             void* stream);
 
 /* ---------------------------------------------------------------- GraphConv on operand planes
  * Second implementation of the same operator (modules.py:194-220) for the layers that carry the step's
@@ -513,6 +517,15 @@ int ofx_gridconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_in, int64_t
                      const float* Wp, int cout, const float* bias, const float* emb, int64_t lde,
                      const int32_t* batch_id, const float* res, int64_t ldr, float* out,
                      int64_t ldc, void* ws, size_t ws_bytes, void* stream);
+/* The same branch-free gather-GEMM with a caller-made table of ntap sources per output row (entries in [0, n_src];
+ * n_src = the zero row): out[orow(r), :] = [ x[tab[r, 0], :] | ... | x[tab[r, ntap - 1], :] ] @ W + bias + res[r].
+ * Downsample (modules.py:391-395) is this with tab[r, j] = 8 r + j, for an x whose row pitch is not its width (a column
+ * slice of the skip-concatenation buffer) -- the reference's x.view(-1, 8 C) would have to copy.  cin % 32 == 0; W packed
+ * as for ofx_gemm_f32 with K = ntap * cin; out_rows / out_mode as in ofx_gemm_f32_planes. */
+int ofx_gather_gemm_f32(const float* x, int64_t ldx, int cin, int ntap, int64_t n_src, int64_t n_out, const int32_t* tab,
+                        const float* zero_row, const float* Wp, int64_t Kp, int cout, const float* bias,
+                        const float* res, int64_t ldr, float* out, int64_t ldc, const int32_t* out_rows, void* ws,
+                        size_t ws_bytes, int out_mode, void* stream);
 int ofx_attention(const float* qkv, int64_t ldq, int batch_size, int T, int heads, int ch,
                   float* out, int64_t ldo, void* stream);
 
@@ -540,6 +553,9 @@ int ofx_gather_mean(const float* x, int64_t ldx, int cin, int64_t n_nodes,
  *            launch finalises on the fly (same arithmetic, same bits; one launch less per norm). */
 int ofx_gn_stats(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,
                  int batch_size, double* sums, void* stream);
+/* ofx_gn_stats without the zero-fill: accumulates into caller-zeroed `sums` (no memset node per statistics launch). */
+int ofx_gn_stats_acc(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id, int batch_size,
+                     double* sums, void* stream);
 int ofx_gn_finalize(const double* sums, const float* count, int batch_size, int C, int groups,
                     float eps, float count_eps, float* mean, float* rstd, void* stream);
 int ofx_gn_apply(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,

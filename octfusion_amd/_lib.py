@@ -93,9 +93,11 @@ _SIGS = {
     'ofx_set_range_words': (c_i, [c_p], True),
     'ofx_get_precision': (c_i, [], False),
     'ofx_gn_apply_rows': (c_i, [], False),
-    'ofx_graphconv_narrow_in': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_sz, c_p], True),
+    'ofx_gather_gemm_f32': (c_i, [c_p, c_l, c_i, c_i, c_l, c_l, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_sz, c_i, c_p], True),
+    'ofx_graphconv_narrow_in': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_sz, c_p], True),
     'ofx_narrow_out_pack': (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p], True),
-    'ofx_graphconv_narrow_out': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_l, c_p], True),
+    'ofx_narrow_out_type_term': (c_i, [c_p, c_l, c_i, c_l, c_p, c_i, c_i, c_p, c_p, c_p], True),
+    'ofx_graphconv_narrow_out': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_l, c_p], True),
     'ofx_packed_floats': (c_l, [c_l, c_l], False),
     'ofx_packed_k': (c_l, [c_l], False),
     'ofx_graphconv_packed_k': (c_l, [c_i, c_i], False),
@@ -132,6 +134,7 @@ _SIGS = {
     'ofx_attention': (c_i, [c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_l, c_p], True),
     'ofx_gather_mean': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p], True),
     'ofx_gn_stats': (c_i, [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_p], True),
+    'ofx_gn_stats_acc': (c_i, [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_p], True),
     'ofx_gn_finalize': (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p], True),
     'ofx_gn_apply': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_i, c_p, c_l, c_p], True),
     'ofx_rows_copy': (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_p], True),

@@ -1148,7 +1148,7 @@ static int launch_gemm(GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st) 
   int rc;
   bool fast;
   if (MODE == MODE_GATHER) {
-    fast = g.fast && g.nbr_ext && g.aux && !g.out_rows;
+    fast = g.fast && g.nbr_ext && g.aux && (!g.out_rows || g.gather_out_rows);
   } else {
     fast = ((g.lda & 3) == 0) && ((g.K & 3) == 0) && g.K >= 4 && ((((uintptr_t)g.A) & 15) == 0);
     if (fast) { g.ndir = 1; g.n_src = 0; g.aux = g.A; g.tf = g.A; g.ldt = g.lda; g.nbr_ext = (const int32_t*)g.A; }
@@ -1820,6 +1820,34 @@ extern "C" int ofx_gridconv_fwd(const float* x, int64_t ldx, int cin, int64_t n_
     rc = launch_gather_via_col(g, (float*)ws, ws_bytes, ofx_stream(stream));
     if (rc >= 0) return rc;
   }
+  return launch_gemm<MODE_GATHER>(g, (float*)ws, ws_bytes, ofx_stream(stream));
+}
+
+// out[orow(r), :] = [ x[tab[r, 0], :] | ... | x[tab[r, ntap - 1], :] ] @ W + bias + res[r]: the branch-free gather-GEMM with
+// a caller-made table -- Downsample (modules.py:391-395: the eight children of a node are rows 8 r .. 8 r + 7, so
+// `x.view(-1, 8 C) @ W` is this with tab[r, j] = 8 r + j) on an x whose rows are NOT contiguous (a column slice of the
+// skip-concatenation buffer: ld != C, where the reference's .view() forces a copy).  Kp = pad32(ntap * cin), W packed as
+// for ofx_gemm_f32 (k = tap * cin + c); out_rows / out_mode as in ofx_gemm_f32_planes.
+extern "C" int ofx_gather_gemm_f32(const float* x, int64_t ldx, int cin, int ntap, int64_t n_src, int64_t n_out,
+                                   const int32_t* tab, const float* zero_row, const float* Wp, int64_t Kp, int cout,
+                                   const float* bias, const float* res, int64_t ldr, float* out, int64_t ldc,
+                                   const int32_t* out_rows, void* ws, size_t ws_bytes, int out_mode, void* stream) {
+  if (n_out == 0 && cin >= 1 && cout >= 1) return OFX_OK;
+  if (ntap < 1 || ntap > 64 || n_src < 1 || !tab || !zero_row || ((uintptr_t)zero_row & 15) || (cin & 31) || (ldx & 3) ||
+      ((uintptr_t)x & 15) || Kp != pad32((int64_t)ntap * cin))
+    return OFX_EINVAL;
+  if (out_mode != 0 && out_mode != 2 && out_mode != 3) return OFX_EINVAL;
+  if (out_mode && ((cout & 3) || (ldc & 31) || ((uintptr_t)out & 127) || (res && ((ldr & 3) || ((uintptr_t)res & 15))) ||
+                   (bias && ((uintptr_t)bias & 15)) || ((uintptr_t)ws & 15)))
+    return OFX_EINVAL;
+  GemmArgs g = {};
+  int rc = gather_common(g, x, ldx, cin, ntap, n_out, tab, nullptr, nullptr, Wp, Kp, cout, bias, nullptr, 0, nullptr, res,
+                         ldr, out, ldc);
+  if (rc) return rc;
+  if (!g.fast) return OFX_EINVAL;
+  g.nbr_ext = tab; g.aux = zero_row; g.ldaux = ldx; g.n_src = n_src;      // entries == n_src name the zero row
+  g.tf = x; g.ldt = ldx;
+  g.out_rows = out_rows; g.gather_out_rows = 1; g.out_planes = out_mode;
   return launch_gemm<MODE_GATHER>(g, (float*)ws, ws_bytes, ofx_stream(stream));
 }
 

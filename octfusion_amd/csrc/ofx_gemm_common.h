@@ -26,6 +26,7 @@ struct GemmArgs {
   const float* emb; int64_t lde; const int32_t* bid;
   const float* res; int64_t ldr;
   float* out; int64_t ldc; const int32_t* out_rows;
+  int gather_out_rows;     // gather mode: the caller vouches for out_rows on the branch-free kernel (ofx_gather_gemm_f32)
   int out_planes;          // 0: fp32 rows; 2 / 3: write `out` as bf16 / fp16 hi + lo pair planes (vec4 epilogues only; needs
                            // a 128-B aligned `out` and ldc % 32 == 0): the consumer is the planes GraphConv
   double* stats; int64_t stats_ld;   // optional fused GroupNorm statistics: stats[(b*stats_ld + n)*2 + {0,1}] += (v, v*v)

@@ -5,11 +5,10 @@
 // roof; output: the register-staged kernel gathering E x 128 floats for 3 output columns, 137 us).  They are gathers:
 //
 //   * narrow_in_kernel: per 64-row block the 7 x (cin + nt) col_data values of every row go to LDS (one thread per
-//     (row, direction) segment walks its CSR edges: 12..32-byte pieces of x, L2 hits), then a lane OWNS 1 or 2 output
-//     columns -- its K weights live in registers for the whole block -- and every row is K broadcast LDS reads + K
-//     FMAs per lane in exact fp32; the 512-B output row of a wave is one coalesced store.  GroupNorm statistics of the
-//     output ride along (per-lane column sums, no cross-lane work) in the two-stage protocol of the MFMA kernels
-//     (stats_part[block][cout][2] -> stats_reduce_kernel).  Bound: the N x cout x 4-byte store stream.
+//     (row, direction) segment walks its CSR edges: 12..32-byte pieces of x, L2 hits), then the [64, K] x [K, cout]
+//     product runs on the exact-fp32 MFMA with a wave's 32-column slice of W held in registers for the whole block.
+//     GroupNorm statistics of the output ride along (per-lane column sums) in the two-stage protocol of the MFMA
+//     kernels (stats_part[block][cout][2] -> stats_reduce_kernel).  Bound: the N x cout x 4-byte store stream.
 //   * narrow_out_kernel: project-then-aggregate.  scatter_mean and the weight product commute, so the caller first
 //     projects every node ONCE, P[j, dir * cout + o] = y[j, :] . W[dir, :, o]  (a dense [N, C] x [C, 7 cout] GEMM that reads y
 //     coalesced), and this kernel gathers cout floats per EDGE instead of C: lane = (row, direction), the seven
@@ -26,121 +25,125 @@ namespace {
 struct NarrowInArgs {
   const float* x; int64_t ldx; int cin; int64_t N;
   const int32_t* seg_ptr; const int32_t* col;
-  const float* tf; int64_t ldt; int nt;
+  const uint8_t* ntype; int nt;
   const float* W; int cout; const float* bias;
   float* out; int64_t ldc;
   const int32_t* bid; float* stats_part; double* stats; int64_t stats_ld;
 };
 
-template <int NC, int KP>
-__global__ void __launch_bounds__(256) narrow_in_kernel(const NarrowInArgs a) {
-  __shared__ __attribute__((aligned(16))) float cd[64][KP];
-  __shared__ float red[3][64 * NC * 2];
+// Loads whose bound is a run-time value are UNCONDITIONAL with a clamped index and a select on the value: a load under
+// `if (k < K)` costs a branch + an s_waitcnt per load (the first version of this kernel spent 64 x an L2 round trip on
+// fetching its weights: 182 us per depth-6 launch against 112 us for the path it replaced).  The contraction is 8 (4)
+// tiles of 32 x 32 on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, K / 2 instructions per tile): the second version ran it
+// as per-lane FMA chains fed by broadcast LDS reads and was bound by those reads (one lgkmcnt(0) per read: 157 us).
+//   wave -> a 32-column slice of W (K / 2 registers: B[k = 2 kk + lane / 32][n = lane % 32]) and one or two 32-row tiles;
+//   A[m = lane % 32][k = 2 kk + lane / 32] comes from LDS with an odd row pitch (conflict-free);
+//   C / D: col = lane % 32, row = (reg & 3) + 8 (reg >> 2) + 4 (lane / 32): a register is two 128-B row pieces.
+// 512 threads: ONE (row, direction) segment per thread -- the gather is a chain of three dependent loads (segment bounds ->
+// column -> x / node type, the first two first-touch HBM misses), and walking two segments per thread in turn made the
+// block's latency two chains long (97 us per depth-6 launch with 256 threads).
+template <int KP, int CI>
+__global__ void __launch_bounds__(512, KP == 64 ? 6 : 4) narrow_in_kernel(const NarrowInArgs a) {
+  constexpr int LD = KP + 1;
+  __shared__ float cd[64 * LD];
+  __shared__ float red[8][32][2];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * 64;
-  const int cpd = a.cin + a.nt, K = 7 * cpd;
+  const int cin = a.cin, nt = a.nt, cpd = cin + nt, K = 7 * cpd;
+  const bool wide = a.cout == 128;          // 4 column slices x 2 row tiles = one tile per wave; else 2 x 2 on waves 0..3
+  const int slice = wide ? (wv & 3) : (wv & 1);
+  const int mt0 = wide ? (wv >> 2) : ((wv >> 1) & 1), nmt = (wide || wv < 4) ? 1 : 0;
+  const int ln = lane & 31, lk = lane >> 5;
 
-  // this lane's columns of W: K x NC registers, loaded while the gather below is in flight
-  float w[KP][NC];
-#pragma unroll
-  for (int k = 0; k < KP; ++k) {
-#pragma unroll
-    for (int j = 0; j < NC; ++j) w[k][j] = k < K ? a.W[(int64_t)k * a.cout + lane * NC + j] : 0.f;
+  // ---- phase 1: col_data of the block's rows -> LDS (zero beyond K and beyond N).  One thread per (row, direction)
+  // segment: mean of the cin channels and of the one-hot node types (modules.py:199-207) over its neighbours.
+  {                                                     // columns K .. KP - 1
+    const int r = tid >> 3;
+    for (int k = K + (tid & 7); k < KP; k += 8) cd[r * LD + k] = 0.f;
   }
-  float bv[NC];
-#pragma unroll
-  for (int j = 0; j < NC; ++j) bv[j] = a.bias ? a.bias[lane * NC + j] : 0.f;
-
-  // ---- phase 1: col_data of the block's rows -> LDS (zero beyond K and beyond N)
-  for (int i = tid; i < 64 * (KP - K); i += 256) cd[i / (KP - K)][K + i % (KP - K)] = 0.f;
-  for (int s = tid; s < 64 * 7; s += 256) {
+  for (int s = tid; s < 64 * 7; s += 512) {
     const int r = s / 7, dir = s - r * 7;
     const int64_t row = row0 + r;
-    float acc[8];
+    float acc[CI], tc[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-    float cnt = 1.f;
-    if (row < a.N) {
-      const int32_t b = a.seg_ptr[row * 7 + dir], e = a.seg_ptr[row * 7 + dir + 1];
-      for (int32_t p = b; p < e; ++p) {
-        const float* xr = a.x + (int64_t)a.col[p] * a.ldx;
+    for (int c = 0; c < CI; ++c) acc[c] = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-          if (c < a.cin) acc[c] += xr[c];
-      }
-      cnt = (float)(e - b > 1 ? e - b : 1);
+    for (int t = 0; t < 8; ++t) tc[t] = 0.f;
+    int32_t b = 0, e = 0;
+    if (row < a.N) { b = a.seg_ptr[row * 7 + dir]; e = a.seg_ptr[row * 7 + dir + 1]; }
+    for (int32_t p = b; p < e; ++p) {
+      const int64_t j = a.col[p];
+      const float* xr = a.x + j * a.ldx;
+      float v[CI];
+#pragma unroll
+      for (int c = 0; c < CI; ++c) v[c] = xr[c < cin ? c : cin - 1];
+      const int ty = nt ? (int)a.ntype[j] : 0;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) acc[c] += v[c];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) tc[t] += ty == t ? 1.f : 0.f;
     }
-    float* o = &cd[r][dir * cpd];
+    const float inv = __frcp_rn((float)(e - b > 1 ? e - b : 1));
+    float* o = &cd[r * LD + dir * cpd];
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-      if (c < a.cin) o[c] = acc[c] / cnt;
-    for (int t = 0; t < a.nt; ++t) o[a.cin + t] = row < a.N ? a.tf[row * a.ldt + dir * a.nt + t] : 0.f;
+    for (int c = 0; c < CI; ++c)
+      if (c < cin) o[c] = acc[c] * inv;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (t < nt) o[cin + t] = tc[t] * inv;
   }
+  // this wave's slice of W as the MFMA's B operand: requested here, after the gather's registers are dead (six waves per
+  // SIMD need <= 80 VGPRs) and before the barrier, so the loads fly while the block's slower threads finish
+  float bw[KP / 2];
+#pragma unroll
+  for (int kk = 0; kk < KP / 2; ++kk) {
+    const int k = 2 * kk + lk;
+    const float v = a.W[(int64_t)(k < K ? k : K - 1) * a.cout + slice * 32 + ln];
+    bw[kk] = k < K ? v : 0.f;
+  }
+  const float bias = a.bias ? a.bias[slice * 32 + ln] : 0.f;
   // do all rows of the block belong to one batch element?  (decides how the statistics leave the block)
   bool same = true;
-  int b0 = 0;
-  if (a.stats) {
-    b0 = a.bid[row0];
-    if (tid < 64 && row0 + tid < a.N) same = a.bid[row0 + tid] == b0;
-  }
+  if (a.stats && tid < 64 && row0 + tid < a.N) same = a.bid[row0 + tid] == a.bid[row0];
   const bool uni = __syncthreads_and(same);
 
-  // ---- phase 2: rows wv * 16 .. + 16 of the block; lane -> columns lane * NC .. + NC
-  float s_[NC], q_[NC];
+  // ---- phase 2: the tiles of this wave
+  float s_ = 0.f, q_ = 0.f;
+  for (int t = 0; t < nmt; ++t) {
+    const int mt = mt0 + t;
+    f32x16 acc;
 #pragma unroll
-  for (int j = 0; j < NC; ++j) s_[j] = q_[j] = 0.f;
-  for (int i = 0; i < 16; ++i) {
-    const int r = wv * 16 + i;
-    const int64_t row = row0 + r;
-    if (row >= a.N) break;
-    float acc[NC];
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float* ap = &cd[(mt * 32 + ln) * LD + lk];
 #pragma unroll
-    for (int j = 0; j < NC; ++j) acc[j] = bv[j];
+    for (int kk = 0; kk < KP / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk], bw[kk], acc, 0, 0, 0);
 #pragma unroll
-    for (int k4 = 0; k4 < KP / 4; ++k4) {
-      if (k4 * 4 < K) {
-        const float4 c = *reinterpret_cast<const float4*>(&cd[r][k4 * 4]);        // same address in every lane: broadcast
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-          acc[j] = fmaf(c.x, w[k4 * 4 + 0][j], acc[j]);
-          acc[j] = fmaf(c.y, w[k4 * 4 + 1][j], acc[j]);
-          acc[j] = fmaf(c.z, w[k4 * 4 + 2][j], acc[j]);
-          acc[j] = fmaf(c.w, w[k4 * 4 + 3][j], acc[j]);
-        }
-      }
-    }
-    float* o = a.out + row * a.ldc + lane * NC;
-    if (NC == 2) *reinterpret_cast<float2*>(o) = make_float2(acc[0], acc[NC - 1]);
-    else o[0] = acc[0];
-    if (a.stats) {
-      if (uni) {
-#pragma unroll
-        for (int j = 0; j < NC; ++j) { s_[j] += acc[j]; q_[j] += acc[j] * acc[j]; }
-      } else {                                           // a block that holds a batch boundary (a handful per launch)
-        double* so = a.stats + ((int64_t)a.bid[row] * a.stats_ld + lane * NC) * 2;
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-          unsafeAtomicAdd(so + 2 * j, (double)acc[j]);
-          unsafeAtomicAdd(so + 2 * j + 1, (double)acc[j] * (double)acc[j]);
+    for (int i = 0; i < 16; ++i) {
+      const int64_t row = row0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk;
+      const float v = acc[i] + bias;
+      if (row < a.N) {
+        a.out[row * a.ldc + slice * 32 + ln] = v;
+        if (a.stats) {
+          if (uni) { s_ += v; q_ += v * v; }
+          else {                                         // a block that holds a batch boundary (a handful per launch)
+            double* so = a.stats + ((int64_t)a.bid[row] * a.stats_ld + slice * 32 + ln) * 2;
+            unsafeAtomicAdd(so, (double)v);
+            unsafeAtomicAdd(so + 1, (double)v * (double)v);
+          }
         }
       }
     }
   }
   if (a.stats) {
     // one partial (sum, sum of squares) per block and column: stats_part[block][cout][2] (zeros for a mixed block)
-    if (wv > 0) {
-#pragma unroll
-      for (int j = 0; j < NC; ++j) { red[wv - 1][(lane * NC + j) * 2] = s_[j]; red[wv - 1][(lane * NC + j) * 2 + 1] = q_[j]; }
-    }
+    s_ += __shfl_xor(s_, 32);
+    q_ += __shfl_xor(q_, 32);
+    if (lk == 0) { red[wv][ln][0] = s_; red[wv][ln][1] = q_; }
     __syncthreads();
-    if (wv == 0) {
-#pragma unroll
-      for (int j = 0; j < NC; ++j) {
-        float s = s_[j], q = q_[j];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) { s += red[u][(lane * NC + j) * 2]; q += red[u][(lane * NC + j) * 2 + 1]; }
-        *reinterpret_cast<float2*>(a.stats_part + ((int64_t)blockIdx.x * a.cout + lane * NC + j) * 2) = make_float2(s, q);
-      }
+    if (tid < a.cout) {                                  // the two row tiles of a slice sit on waves sl and sl + 4 (sl + 2)
+      const int sl = tid >> 5, j = tid & 31, o = wide ? 4 : 2;
+      *reinterpret_cast<float2*>(a.stats_part + ((int64_t)blockIdx.x * a.cout + tid) * 2) =
+          make_float2(red[sl][j][0] + red[sl + o][j][0], red[sl][j][1] + red[sl + o][j][1]);
     }
   }
 }
@@ -148,12 +151,49 @@ __global__ void __launch_bounds__(256) narrow_in_kernel(const NarrowInArgs a) {
 struct NarrowOutArgs {
   const float* P; int64_t ldp; int cout; int64_t N;
   const int32_t* seg_ptr; const int32_t* col;
-  const float* tf; int64_t ldt; int nt;
-  const float* W; int64_t w_type_row0; int w_dir_stride;      // type rows of direction d start at W row d * w_dir_stride + w_type_row0
-  const float* bias; float* out; int64_t ldc;
+  const float* tt;                                   // [N, cout]: node-type term + bias of every row (narrow_type_term_kernel)
+  float* out; int64_t ldc;
 };
 
-// lane = (row, slot): slots 0..6 = the seven directions, slot 7 = bias.  32 rows per 256-thread block.
+// tt[r, o] = bias[o] + sum_{dir, t} type_frac[r, dir * nt + t] * W[dir * (C + nt) + C + t, o]: constant per (doctree depth,
+// weights), computed once and cached by the caller; lane = (row, direction) like the aggregation kernel.
+template <int CO>
+__global__ void __launch_bounds__(256) narrow_type_term_kernel(const float* __restrict__ tf, int64_t ldt, int nt, int64_t N,
+                                                                const float* __restrict__ W, int C, int cout,
+                                                                const float* __restrict__ bias, float* __restrict__ tt) {
+  const int tid = threadIdx.x, d = tid & 7;
+  const int64_t row = (int64_t)blockIdx.x * 32 + (tid >> 3);
+  float acc[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+  if (row < N) {
+    if (d < 7) {
+      for (int t = 0; t < nt; ++t) {
+        const float f = tf[row * ldt + d * nt + t];
+        const float* wr = W + ((int64_t)d * (C + nt) + C + t) * cout;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] = fmaf(f, wr[o < cout ? o : 0], acc[o]);
+      }
+    } else if (bias) {
+#pragma unroll
+      for (int o = 0; o < CO; ++o) acc[o] = bias[o < cout ? o : 0];
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    acc[o] += __shfl_xor(acc[o], 1);
+    acc[o] += __shfl_xor(acc[o], 2);
+    acc[o] += __shfl_xor(acc[o], 4);
+  }
+  if (d == 0 && row < N) {
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+      if (o < cout) tt[row * cout + o] = acc[o];
+  }
+}
+
+// lane = (row, slot): slots 0..6 = the seven directions (three dependent loads: segment bounds -> column -> cout floats of
+// P), slot 7 = the row's cached type term.  32 rows per 256-thread block; the eight lanes of a row meet by xor-shuffles.
 template <int CO>
 __global__ void __launch_bounds__(256) narrow_out_kernel(const NarrowOutArgs a) {
   const int tid = threadIdx.x;
@@ -167,25 +207,21 @@ __global__ void __launch_bounds__(256) narrow_out_kernel(const NarrowOutArgs a) 
       const int32_t b = a.seg_ptr[row * 7 + d], e = a.seg_ptr[row * 7 + d + 1];
       for (int32_t p = b; p < e; ++p) {
         const float* pr = a.P + (int64_t)a.col[p] * a.ldp + d * a.cout;
+        float v[CO];
 #pragma unroll
-        for (int o = 0; o < CO; ++o)
-          if (o < a.cout) acc[o] += pr[o];
+        for (int o = 0; o < CO; ++o) v[o] = pr[o < a.cout ? o : 0];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] += v[o];
       }
       const float cnt = (float)(e - b > 1 ? e - b : 1);
 #pragma unroll
-      for (int o = 0; o < CO; ++o) acc[o] /= cnt;
-      // node-type term of this direction: sum_t type_frac[row, d, t] * W[d, C + t, :]
-      for (int t = 0; t < a.nt; ++t) {
-        const float f = a.tf[row * a.ldt + d * a.nt + t];
-        const float* wr = a.W + ((int64_t)d * a.w_dir_stride + a.w_type_row0 + t) * a.cout;
+      for (int o = 0; o < CO; ++o) acc[o] = o < a.cout ? acc[o] / cnt : 0.f;
+    } else if (a.tt) {
 #pragma unroll
-        for (int o = 0; o < CO; ++o)
-          if (o < a.cout) acc[o] = fmaf(f, wr[o], acc[o]);
+      for (int o = 0; o < CO; ++o) {
+        const float v = a.tt[row * a.cout + (o < a.cout ? o : 0)];
+        acc[o] = o < a.cout ? v : 0.f;
       }
-    } else if (a.bias) {
-#pragma unroll
-      for (int o = 0; o < CO; ++o)
-        if (o < a.cout) acc[o] = a.bias[o];
     }
   }
 #pragma unroll
@@ -214,26 +250,23 @@ __global__ void narrow_out_pack_kernel(const float* __restrict__ W, int C, int n
 }  // namespace
 
 extern "C" int ofx_graphconv_narrow_in(const float* x, int64_t ldx, int cin, int64_t n_nodes, const int32_t* seg_ptr,
-                                       const int32_t* col, const float* type_frac, int64_t ldt, int nt, const float* W,
-                                       int cout, const float* bias, const int32_t* batch_id, float* out, int64_t ldc,
-                                       double* stats, int64_t stats_ld, void* ws, size_t ws_bytes, void* stream) {
-  if (!x || !seg_ptr || !col || !W || !out || cin < 1 || cin > 8 || ldx < cin || nt < 0 || (nt > 0 && (!type_frac || ldt < 7 * nt)) ||
-      (cout != 64 && cout != 128) || ldc < cout || (ldc & 1) || ((uintptr_t)out & 7) || n_nodes < 0 || 7 * (cin + nt) > 96)
+                                       const int32_t* col, const uint8_t* node_type, int nt, const float* W, int cout,
+                                       const float* bias, const int32_t* batch_id, float* out, int64_t ldc, double* stats,
+                                       int64_t stats_ld, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !seg_ptr || !col || !W || !out || cin < 1 || cin > 8 || ldx < cin || nt < 0 || nt > 8 || (nt > 0 && !node_type) ||
+      (cout != 64 && cout != 128) || ldc < cout || n_nodes < 0 ||
+      7 * (cin + nt) > 96)
     return OFX_EINVAL;
   if (n_nodes == 0) return OFX_OK;
   const int64_t nblk = ofx_cdiv(n_nodes, 64);
   if (stats && (!batch_id || stats_ld < cout || !ws || ws_bytes < (size_t)nblk * cout * 2 * sizeof(float))) return OFX_EINVAL;
   hipStream_t st = ofx_stream(stream);
-  NarrowInArgs a = {x, ldx, cin, n_nodes, seg_ptr, col, type_frac, ldt, nt, W, cout, bias, out, ldc,
+  NarrowInArgs a = {x, ldx, cin, n_nodes, seg_ptr, col, node_type, nt, W, cout, bias, out, ldc,
                     batch_id, (float*)ws, stats, stats_ld};
   const int K = 7 * (cin + nt);
-  if (cout == 128) {
-    if (K <= 64) narrow_in_kernel<2, 64><<<(unsigned)nblk, 256, 0, st>>>(a);
-    else narrow_in_kernel<2, 96><<<(unsigned)nblk, 256, 0, st>>>(a);
-  } else {
-    if (K <= 64) narrow_in_kernel<1, 64><<<(unsigned)nblk, 256, 0, st>>>(a);
-    else narrow_in_kernel<1, 96><<<(unsigned)nblk, 256, 0, st>>>(a);
-  }
+  const unsigned nb = (unsigned)nblk;
+  if (K <= 64) { if (cin <= 4) narrow_in_kernel<64, 4><<<nb, 512, 0, st>>>(a); else narrow_in_kernel<64, 8><<<nb, 512, 0, st>>>(a); }
+  else { if (cin <= 4) narrow_in_kernel<96, 4><<<nb, 512, 0, st>>>(a); else narrow_in_kernel<96, 8><<<nb, 512, 0, st>>>(a); }
   OFX_LAUNCH_CHECK();
   if (stats) {
     GemmArgs g = {};
@@ -250,14 +283,24 @@ extern "C" int ofx_narrow_out_pack(const float* W, int C, int nt, int cout, int 
   return OFX_OK;
 }
 
-extern "C" int ofx_graphconv_narrow_out(const float* P, int64_t ldp, int cout, int64_t n_nodes, const int32_t* seg_ptr,
-                                        const int32_t* col, const float* type_frac, int64_t ldt, int nt, const float* W,
-                                        int C, const float* bias, float* out, int64_t ldc, void* stream) {
-  if (!P || !seg_ptr || !col || !W || !out || cout < 1 || cout > 8 || ldp < 7 * cout || nt < 0 ||
-      (nt > 0 && (!type_frac || ldt < 7 * nt)) || C < 1 || ldc < cout || n_nodes < 0)
+extern "C" int ofx_narrow_out_type_term(const float* type_frac, int64_t ldt, int nt, int64_t n_nodes, const float* W, int C,
+                                        int cout, const float* bias, float* tt, void* stream) {
+  if (!W || !tt || C < 1 || cout < 1 || cout > 8 || nt < 0 || (nt > 0 && (!type_frac || ldt < 7 * nt)) || n_nodes < 0)
     return OFX_EINVAL;
   if (n_nodes == 0) return OFX_OK;
-  NarrowOutArgs a = {P, ldp, cout, n_nodes, seg_ptr, col, type_frac, ldt, nt, W, (int64_t)C, C + nt, bias, out, ldc};
+  const unsigned nblk = (unsigned)ofx_cdiv(n_nodes, 32);
+  hipStream_t st = ofx_stream(stream);
+  if (cout <= 4) narrow_type_term_kernel<4><<<nblk, 256, 0, st>>>(type_frac, ldt, nt, n_nodes, W, C, cout, bias, tt);
+  else narrow_type_term_kernel<8><<<nblk, 256, 0, st>>>(type_frac, ldt, nt, n_nodes, W, C, cout, bias, tt);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+extern "C" int ofx_graphconv_narrow_out(const float* P, int64_t ldp, int cout, int64_t n_nodes, const int32_t* seg_ptr,
+                                        const int32_t* col, const float* type_term, float* out, int64_t ldc, void* stream) {
+  if (!P || !seg_ptr || !col || !out || cout < 1 || cout > 8 || ldp < 7 * cout || ldc < cout || n_nodes < 0) return OFX_EINVAL;
+  if (n_nodes == 0) return OFX_OK;
+  NarrowOutArgs a = {P, ldp, cout, n_nodes, seg_ptr, col, type_term, out, ldc};
   hipStream_t st = ofx_stream(stream);
   const unsigned nblk = (unsigned)ofx_cdiv(n_nodes, 32);
   if (cout <= 4) narrow_out_kernel<4><<<nblk, 256, 0, st>>>(a);

@@ -118,6 +118,19 @@ extern "C" int ofx_gn_stats(const float* x, int64_t ldx, int64_t n, int C, const
   return OFX_OK;
 }
 
+// The same, ACCUMULATING into `sums` (the caller zeroed it: one fill per network forward for all statistics buffers
+// instead of a memset node in front of every statistics launch of a captured step).
+extern "C" int ofx_gn_stats_acc(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id, int batch_size,
+                                double* sums, void* stream) {
+  if (!x || !batch_id || !sums || n < 0 || C < 4 || (C & 3) || C > 1024 || ldx < C || (ldx & 3) ||
+      ((uintptr_t)x & 15) || batch_size < 1)
+    return OFX_EINVAL;
+  if (n > 0) gn_stats_kernel<<<(int)ofx_cdiv(n, gn_stats_rows(n, batch_size, C)), 256, 0, ofx_stream(stream)>>>(
+      x, ldx, n, C, batch_id, sums, gn_stats_rows(n, batch_size, C));
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
 __global__ void gn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ count, int B, int C, int G,
                                    float eps, float count_eps, float* __restrict__ mean, float* __restrict__ rstd) {
   const int cpg = C / G;

@@ -212,6 +212,10 @@ class DualOctree:
         """int32 [N*7]: the single neighbour of segment (row, dir), -1 none, -2 several (see csr)."""
         return self._nbr[d]
 
+    def node_type8(self, d):
+        """uint8 [N_d]: node type of every row of graph depth d (the one-hot class of modules.py:199-203)."""
+        return self._ntype8[d]
+
     def ext(self, d):
         """(nbr_ext int32 [N*7], multi_seg int32 [V], V): the branch-free gather table (ofx.h)."""
         return self._ext[d]

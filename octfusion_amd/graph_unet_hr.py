@@ -7,6 +7,8 @@ same ``forward`` / ``forward_as_middle`` signatures, same state_dict keys
 output_blocks.N.*, end_norm.*, out.weights).  The block list is generated from a
 level plan instead of the reference's nested loops; every block runs on libofx.
 """
+import inspect
+
 import torch
 import torch.nn as nn
 
@@ -136,17 +138,19 @@ class UNet3DModel(nn.Module):
             off += l.out_features
         return outs
 
-    def forward_as_middle(self, h, doctree, timesteps, label, context):
+    def forward_as_middle(self, h, doctree, timesteps, label, context, out=None):
+        """reference graph_unet_hr.py:211-212; ``out``: optional destination rows (a column slice of the caller's
+        concatenation buffer)."""
         return self.forward(x=h, doctree=doctree, timesteps=timesteps, label=label, context=context,
-                            as_middle=True)
+                            as_middle=True, out=out)
 
     @torch.no_grad()
     def forward(self, x=None, doctree=None, unet_lr=None, timesteps=None, label=None, context=None,
-                as_middle=False, **kwargs):
+                as_middle=False, out=None, **kwargs):
         with ops.stats_scope(x.device):           # one zero-fill for every fused GroupNorm statistics buffer
-            return self._forward(x, doctree, unet_lr, timesteps, label, context, as_middle)
+            return self._forward(x, doctree, unet_lr, timesteps, label, context, as_middle, out)
 
-    def _forward(self, x, doctree, unet_lr, timesteps, label, context, as_middle):
+    def _forward(self, x, doctree, unet_lr, timesteps, label, context, as_middle, out_mid=None):
         assert (label is not None) == (self.num_classes is not None), \
             'must specify y if and only if the model is class-conditional'
         timesteps = timesteps.float()
@@ -209,9 +213,20 @@ class UNet3DModel(nn.Module):
         d = self._d_mid
 
         if unet_lr is not None:
-            h = self.middle_block1(h, emb, doctree, d, emb_act=emb_act, emb_out=emb_outs[id(self.middle_block1)])
-            h_lr = unet_lr.forward_as_middle(h, doctree, timesteps, label, context)
-            h = ops.cat_channels(h, h_lr)
+            # cat([h, h_lr], dim=1) (graph_unet_hr.py:252) without the copy: middle_block1 writes the left columns of one
+            # buffer, the nested net's last GroupNorm the right ones (`out=` is this package's extension of
+            # forward_as_middle; a nested net without it gets a plain concatenation)
+            c_mid = self.middle_block1.out_channels
+            mid = torch.empty(n_at[d], 2 * c_mid, dtype=torch.float32, device=dev)
+            h = self.middle_block1(h, emb, doctree, d, emb_act=emb_act, out=mid[:, :c_mid], emb_out=emb_outs[id(self.middle_block1)])
+            if 'out' in inspect.signature(unet_lr.forward_as_middle).parameters:
+                h_lr = unet_lr.forward_as_middle(h, doctree, timesteps, label, context, out=mid[:, c_mid:])
+            else:
+                h_lr = unet_lr.forward_as_middle(h, doctree, timesteps, label, context)
+            if h_lr.data_ptr() == mid[:, c_mid:].data_ptr() and h_lr.shape[1] == c_mid:
+                h = ops.cat_channels(h, h_lr, buf=mid)
+            else:
+                h = ops.cat_channels(h, h_lr)
             h = self.middle_block2(h, emb, doctree, d, emb_act=emb_act, emb_out=emb_outs[id(self.middle_block2)])
 
         # decoder: block j consumes skip len(hs)-1-j; its own output goes to the left columns of the NEXT
@@ -241,7 +256,7 @@ class UNet3DModel(nn.Module):
             else:
                 pending = module(pending, doctree, dd, out=out_slot)
         h = pending
-        h = self.end_norm(h, doctree, self.input_depth, act='silu')
+        h = self.end_norm(h, doctree, self.input_depth, act='silu', out=out_mid if as_middle else None)
         if as_middle:
             return h
         out = self.out(h, doctree, self.input_depth)

@@ -253,7 +253,7 @@ class ResnetBlock(nn.Module):
         # the 1x1 residual convolution only needs x: a parallel branch (ops.fork_stream), joined before conv2 adds it
         skip, main, fork = x, None, None
         if not isinstance(self.res_conv, nn.Identity):
-            main, fork = ops.fork_stream(x.device)
+            main, fork = ops.fork_stream(x.device, level=2)
             if fork is not None:
                 with torch.cuda.stream(fork):
                     skip = self.res_conv(x)
@@ -406,11 +406,11 @@ class UNet3DModel(nn.Module):
         return outs
 
     @torch.no_grad()
-    def forward_rows(self, x, batch_size, timesteps, label=None, as_middle=False):
+    def forward_rows(self, x, batch_size, timesteps, label=None, as_middle=False, out=None):
         """x [B*8^full_depth, C] in node-row layout; returns rows at full_depth.  (ops.POLICY['dense_net'] can move this
         net to another contraction mode when the global mode is 'bf16x3' -- an instrument of the precision study.)"""
-        with ops.policy_scope('dense_net'):
-            return self._forward_rows(x, batch_size, timesteps, label, as_middle)
+        with ops.policy_scope('dense_net'), ops.stats_scope(x.device):
+            return self._forward_rows(x, batch_size, timesteps, label, as_middle, out)
 
     @torch.no_grad()
     def precompute_embeddings(self, timesteps, label, batch_size):
@@ -425,7 +425,7 @@ class UNet3DModel(nn.Module):
             tms = self._all_time_mlps(emb_act)
         self._pre = (timesteps, label, batch_size, emb_act, tms, main, fork)
 
-    def _forward_rows(self, x, batch_size, timesteps, label, as_middle):
+    def _forward_rows(self, x, batch_size, timesteps, label, as_middle, out=None):
         gs = GridState(batch_size, self.full_depth, x.device)
         if not as_middle:
             x = self.input_emb(x, gs)
@@ -473,14 +473,15 @@ class UNet3DModel(nn.Module):
             x = run_attn(self_attn, resnet(x, emb_act, gs, t=tms[id(resnet)]), gs)
             nxt = bufs[i - 1][:, :cout[i - 1]] if i - 1 in bufs else None
             x, gs = upsample(x, gs, out=nxt)
-        x = self.end[0](x, gs, act='silu')
+        x = self.end[0](x, gs, act='silu', out=out if as_middle else None)
         return x if as_middle else self.out(x, gs)
 
     # ---- reference signatures ---------------------------------------------
     @torch.no_grad()
-    def forward_as_middle(self, h, doctree, timesteps, label, context):
-        # rows of the full layer ARE the dense grid: no octree2voxel / gather-back needed
-        return self.forward_rows(h, doctree.batch_size, timesteps, label, as_middle=True)
+    def forward_as_middle(self, h, doctree, timesteps, label, context, out=None):
+        # rows of the full layer ARE the dense grid: no octree2voxel / gather-back needed.  ``out``: optional destination
+        # rows (a column slice of the caller's concatenation buffer -- the sparse net's cat([h, h_lr]) without a copy)
+        return self.forward_rows(h, doctree.batch_size, timesteps, label, as_middle=True, out=out)
 
     @torch.no_grad()
     def forward(self, x=None, timesteps=None, x_self_cond=None, label=None, context=None, as_middle=False,

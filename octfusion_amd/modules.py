@@ -95,15 +95,21 @@ class GraphConv(nn.Module):
             # the two gather-shaped layers of a U-Net (csrc/ofx_narrow.hip): its input and its output convolution
             if ops.narrow_in_ok(self.in_channels, self.out_channels, nt):
                 y = ops.graphconv_narrow_in(x, seg_ptr, col, self.weights, self.in_channels, nt,
-                                            doctree.type_frac(d, nt) if nt else None, self.bias if self.use_bias else None,
+                                            doctree.node_type8(d) if nt else None, self.bias if self.use_bias else None,
                                             doctree.batch_id32(d) if stats is not None else None, out, stats)
                 if stats is not None:
                     setattr(y, ops.STATS_ATTR, stats)
                 return y
             if ops.NARROW_OUT and self.out_channels <= 8 and self.in_channels % 32 == 0 and N >= 4096:
-                return ops.graphconv_narrow_out(x, seg_ptr, col, self._pno.get(self.weights, self.in_channels, nt),
-                                                self.in_channels, nt, doctree.type_frac(d, nt) if nt else None,
-                                                self.bias if self.use_bias else None, out)
+                pno = self._pno.get(self.weights, self.in_channels, nt)
+                bias = self.bias if self.use_bias else None
+                # node-type term + bias of every row: constant per (doctree depth, weights), cached on the doctree
+                tkey = ('narrow_tt', d, nt, self.weights.data_ptr(), self.weights._version,
+                        None if bias is None else (bias.data_ptr(), bias._version))
+                tt = doctree._tf.get(tkey)
+                if tt is None and (nt or bias is not None):
+                    tt = doctree._tf[tkey] = pno.type_term(doctree.type_frac(d, nt) if nt else None, nt, N, self.in_channels, bias)
+                return ops.graphconv_narrow_out(x, seg_ptr, col, pno, self.in_channels, tt, out)
         if not mode and split_input:
             mode = self.planes_mode(doctree, d)
             if mode:
@@ -264,10 +270,31 @@ class Downsample(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, out=None, out_rows=None, out_planes=0):
-        return ops.gemm(x.reshape(-1, self.channels * 8), self.packed(), out=out, out_rows=out_rows, out_planes=out_planes)
+        C = self.channels
+        if x.stride(0) != C and x.stride(1) == 1 and C % 32 == 0 and x.shape[0] % 8 == 0 and x.shape[0] and ops.zero_row(x.device).numel() >= C:
+            # x is a column slice of a wider buffer (the zero-copy skip concatenation): x.view(-1, 8 C) would copy it
+            # (two strided ATen copies per hr step, 47 us, until round 5) -- gather the eight children instead
+            n = x.shape[0] // 8
+            tab = _child_table(n, x.device)
+            return ops.gather_gemm(x, tab, 8, self.packed(), n, out=out, out_rows=out_rows, out_planes=out_planes)
+        return ops.gemm(x.reshape(-1, C * 8), self.packed(), out=out, out_rows=out_rows, out_planes=out_planes)
 
     def extra_repr(self):
         return 'channels={}'.format(self.channels)
+
+
+_CHILD_TABLES = {}
+
+
+def _child_table(n, device):
+    """int32 [n, 8]: row 8 r + j (the j-th child of node r) -- the gather table of Downsample; cached per size."""
+    key = (n, device.type, device.index)
+    t = _CHILD_TABLES.get(key)
+    if t is None:
+        if len(_CHILD_TABLES) > 64:
+            _CHILD_TABLES.clear()
+        t = _CHILD_TABLES[key] = torch.arange(8 * n + 8, dtype=torch.int32, device=device)     # (+ 32 B of slack behind the last entry)
+    return t
 
 
 class Upsample(nn.Module):

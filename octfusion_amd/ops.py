@@ -279,14 +279,15 @@ def side_stream(device):
 # is consumed.  Inside a captured step these become parallel branches of the hipGraph: ~19 launches of 5-15 us leave
 # the step's critical path.  (The sparse net's 1x1 skip convolutions stay on the main stream: next to a persistent
 # GraphConv launch that owns every CU they were measured slower, OFX_SIDE_STREAM above.)
-FORK = os.environ.get('OFX_FORK', '1') == '1'
+FORK = int(os.environ.get('OFX_FORK', '0'))      # 0: off; 1: the embedding chains; 2: + the dense net's residual 1x1 convolutions
 _FORK = {}
 
 
-def fork_stream(device):
-    """(main, fork) streams of `device` when forking is on and the tensor lives on a HIP device, else (None, None).  The
-    fork stream is NOT sampler.sample_loop's warm-up / capture stream (side_stream): a fork happens inside a step."""
-    if not FORK or device.type != 'cuda':
+def fork_stream(device, level=1):
+    """(main, fork) streams of `device` when forking is on (FORK >= level) and the tensor lives on a HIP device, else
+    (None, None).  The fork stream is NOT sampler.sample_loop's warm-up / capture stream (side_stream): a fork happens
+    inside a step."""
+    if FORK < level or device.type != 'cuda':
         return None, None
     s = _FORK.get(device.index)
     if s is None:
@@ -501,6 +502,29 @@ def gemm(a, pw, bias=None, res=None, out=None, a_rows=None, out_rows=None, m=Non
     return out
 
 
+def gather_gemm(x, tab, ntap, pw, n_out, bias=None, res=None, out=None, out_rows=None, out_planes=0):
+    """out[orow(r)] = concat_j x[tab[r, j]] @ W (+ bias + res[r]): the branch-free gather-GEMM with a caller-made table
+    (ofx_gather_gemm_f32) -- Downsample on an x whose rows are not contiguous."""
+    x, ldx = _row_major(x)
+    cin = x.shape[1]
+    assert pw.K == ntap * cin and cin % 32 == 0
+    _chk(tab, torch.int32)
+    if out is None:
+        out = torch.empty(n_out, pw.N, dtype=torch.float32, device=x.device)
+    out2, ldc = _row_major(out)
+    assert out2 is out
+    ldr = 0
+    if res is not None:
+        res, ldr = _row_major(res)
+    _chk(bias)
+    _chk(out_rows, torch.int32)
+    ws = workspace(x.device)
+    _meta('dense_gemm', 2.0 * n_out * pw.K * pw.N, 4.0 * (n_out * pw.K + pw.K * pw.N + n_out * pw.N), (n_out, pw.K, pw.N))
+    call('ofx_gather_gemm_f32', ptr(x), ldx, cin, ntap, x.shape[0], n_out, ptr(tab), ptr(zero_row(x.device)), ptr(pw.t), pw.Kp,
+         pw.N, ptr(bias), ptr(res), ldr, ptr(out), ldc, ptr(out_rows), ptr(ws), ws.numel(), out_planes, stream())
+    return out
+
+
 LINEAR_SMALL = True          # A/B switch: False sends the few-row linears through the MFMA GEMM again
 
 
@@ -615,9 +639,9 @@ def narrow_in_ok(cin, cout, nt):
     return NARROW_IN and cin <= 8 and cout in (64, 128) and 7 * (cin + nt) <= 96
 
 
-def graphconv_narrow_in(x, seg_ptr, col, weights, cin, nt, type_frac=None, bias=None, batch_id=None, out=None, stats=None):
+def graphconv_narrow_in(x, seg_ptr, col, weights, cin, nt, node_type=None, bias=None, batch_id=None, out=None, stats=None):
     """The U-Net's INPUT GraphConv (3 / 8 channels -> 64 / 128): gather + exact-fp32 FMA with the weights in registers
-    (ofx_graphconv_narrow_in).  weights: the raw nn.Parameter [7 * (cin + nt), cout]."""
+    (ofx_graphconv_narrow_in).  weights: the raw nn.Parameter [7 * (cin + nt), cout]; node_type: uint8 [N]."""
     x, ldx = _row_major(x)
     w = weights.detach()
     if not w.is_contiguous():
@@ -629,10 +653,8 @@ def graphconv_narrow_in(x, seg_ptr, col, weights, cin, nt, type_frac=None, bias=
         out = torch.empty(N, cout, dtype=torch.float32, device=x.device)
     out2, ldc = _row_major(out)
     assert out2 is out
-    ldt = 0
     if nt:
-        _chk(type_frac)
-        ldt = type_frac.stride(0)
+        _chk(node_type, torch.uint8)
     _chk(bias)
     _chk(stats, torch.float64)
     if stats is not None:
@@ -647,7 +669,7 @@ def graphconv_narrow_in(x, seg_ptr, col, weights, cin, nt, type_frac=None, bias=
     flops = 2.0 * N * w.shape[0] * cout
     nbytes = 4.0 * (E * cin + N * cout + w.numel()) + 8.0 * E
     _meta('graphconv_narrow', flops, nbytes, (N, cin, cout, 'narrow_in'))
-    call('ofx_graphconv_narrow_in', ptr(x), ldx, cin, N, ptr(seg_ptr), ptr(col), ptr(type_frac) if nt else None, ldt, nt,
+    call('ofx_graphconv_narrow_in', ptr(x), ldx, cin, N, ptr(seg_ptr), ptr(col), ptr(node_type) if nt else None, nt,
          ptr(w), cout, ptr(bias), ptr(batch_id) if stats is not None else None, ptr(out), ldc, ptr(stats), cout,
          ptr(ws), ws.numel(), stream())
     if prof is not None:
@@ -678,8 +700,18 @@ class PackedNarrowOut:
             self.key = key
         return self
 
+    def type_term(self, type_frac, nt, N, C, bias):
+        """[N, cout] = bias + the node-type part of the convolution: constant per (graph depth, weights) -- the caller
+        caches it on the doctree (ofx_narrow_out_type_term)."""
+        cout = self.w.shape[1]
+        tt = torch.empty(N, cout, dtype=torch.float32, device=self.w.device)
+        _chk(bias)
+        call('ofx_narrow_out_type_term', ptr(type_frac) if nt else None, type_frac.stride(0) if nt else 0, nt, N, ptr(self.w),
+             C, cout, ptr(bias), ptr(tt), stream())
+        return tt
 
-def graphconv_narrow_out(x, seg_ptr, col, pno, C, nt, type_frac=None, bias=None, out=None):
+
+def graphconv_narrow_out(x, seg_ptr, col, pno, C, type_term=None, out=None):
     """The U-Net's OUTPUT GraphConv (C channels -> 3 / 8) as project-then-aggregate: one dense GEMM P = x @ Wd (x read once,
     coalesced), then a gather of cout floats per edge (ofx_graphconv_narrow_out)."""
     N = x.shape[0]
@@ -694,17 +726,14 @@ def graphconv_narrow_out(x, seg_ptr, col, pno, C, nt, type_frac=None, bias=None,
         out = torch.empty(N, cout, dtype=torch.float32, device=x.device)
     out2, ldc = _row_major(out)
     assert out2 is out
-    ldt = 0
-    if nt:
-        _chk(type_frac)
-        ldt = type_frac.stride(0)
-    _chk(bias)
+    _chk(type_term)
+    assert type_term is None or (type_term.is_contiguous() and tuple(type_term.shape) == (N, cout))
     E = col.numel()
     flops = 2.0 * N * pno.w.shape[0] * cout
     nbytes = 4.0 * (E * C + N * cout + pno.w.numel()) + 8.0 * E         # the operator's algorithmic bytes, not this path's
     _meta('graphconv_narrow', flops, nbytes, (N, C, cout, 'narrow_out'))
-    call('ofx_graphconv_narrow_out', ptr(P), P.stride(0), cout, N, ptr(seg_ptr), ptr(col), ptr(type_frac) if nt else None,
-         ldt, nt, ptr(pno.w), C, ptr(bias), ptr(out), ldc, stream())
+    call('ofx_graphconv_narrow_out', ptr(P), P.stride(0), cout, N, ptr(seg_ptr), ptr(col), ptr(type_term), ptr(out), ldc,
+         stream())
     if prof is not None:
         e1.record()
         prof.append((e0, e1, flops, nbytes, cout, ('graph', N, C, cout)))
@@ -939,9 +968,14 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         assert stats.numel() == batch_size * C * 2
         sums = stats
     else:
-        sums = torch.empty(batch_size * C * 2, dtype=torch.float64, device=dev)
         _meta('gn_stats', 0, 4.0 * n * C, (n, C))
-        call('ofx_gn_stats', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
+        p = _stats_pool
+        if p.depth > 0 and p.buf.device == dev and p.cur + batch_size * C * 2 <= p.SIZE:
+            sums = stats_zeros(batch_size * C * 2, dev)          # pre-zeroed pool slice: no memset node in the step
+            call('ofx_gn_stats_acc', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
+        else:
+            sums = torch.empty(batch_size * C * 2, dtype=torch.float64, device=dev)
+            call('ofx_gn_stats', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
     # mean / rstd are derived from the sums inside the apply launch (ofx.h: no ofx_gn_finalize launch) -- except when
     # the launch also writes the consuming GraphConv's aux rows: an aux block's work is a chain of dependent loads
     # (segment -> edge range -> column -> row) and deriving the statistics first makes the chain longer.  Measured twice:

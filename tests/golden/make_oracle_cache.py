@@ -24,7 +24,7 @@ import torch  # noqa: E402
 
 import oracle_cache as OC  # noqa: E402
 
-MODULES = ['test_gpu_fullwidth', 'test_gpu_precision', 'test_gpu_persistent']
+MODULES = ['test_gpu_fullwidth', 'test_gpu_precision', 'test_gpu_persistent', 'test_gpu_feature_b8']
 
 
 def main():

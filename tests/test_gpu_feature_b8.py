@@ -1,0 +1,168 @@
+"""BASELINE configs[4] at its PER-GPU size (VERDICT r04 weak #1a): the Objaverse feature stage on the shell-8 batch of
+EIGHT shapes, N = 3 248 400 nodes -- the size `bench.py --workload feature` runs, until round 5 only touched by the
+bench's own spot check.  Reference: models/networks/diffusion_networks/graph_unet_hr.py:214-281 with the hr net as its
+middle (octfusion_model_union_3t.py:152-214), configs/octfusion_obja_uncond.yaml:11-24.
+
+A whole fp64 oracle step at this size is minutes of CPU and > 60 GB, so:
+  * single layers against the oracle in FLOAT64 on a seeded sample of 8 192 output rows (the oracle's own
+    scatter_mean / one-hot / matmul sequence of modules.py:194-220 restricted to the edges of those rows; fixture
+    `feature_b8_layers`, computed once on the CPU by tests/golden/make_oracle_cache.py): the network's first GraphConv
+    (3 -> 64 at depth 8, the gather kernel), a 64 -> 64 depth-8 GraphConv (planes kernel, persistent launch: 12 690 row
+    tiles), the last one (64 -> 3, project-then-aggregate), and a DualOctreeGroupNorm over all 3.25 M rows (fp64 statistics
+    of the whole tensor, sampled rows compared);
+  * the whole step through size-independent properties: finite, bounded output statistics, and batch EQUIVARIANCE --
+    shapes b and b + 4 of the synthetic batch have the same tree (radius jitter 0.25 (b mod 4)), so with equal input rows
+    they must produce equal output rows although they sit in different tiles, waves and statistics runs.
+"""
+import pytest
+import torch
+
+import common as C
+import oracle_cache as OC
+from test_gpu_fullwidth import dev, errors, report
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+N8 = 3248400
+SAMPLE = 8192
+
+
+def _sample_rows(n):
+    g = torch.Generator().manual_seed(20250805)
+    idx = torch.randperm(n, generator=g)[:SAMPLE - 64]
+    return torch.unique(torch.cat([idx, torch.arange(32), torch.arange(n - 32, n)]))
+
+
+def _b8_oracle_tree():
+    """Oracle dual octree of the bench's feature tree (shell-6 x 8 with radius jitter, grown to shell-8) -- CPU only."""
+    from octfusion_amd import synthetic
+    from oracle import dual_octree as OD, sampler as OS
+    o6 = OS.split2octree_small(synthetic.shell6_split(8, jitter=True), 6, 4)
+    x6, y6, z6, _ = o6.xyzb(6)
+    o_doc = OD.OracleDualOctree(OS.split2octree_large(o6, synthetic.shell8_split_large(x6, y6, z6), 6))
+    o_doc.post_processing_for_docnn()
+    return o_doc
+
+
+def _conv_rows(x, o_doc, d, weights, n_node_type, rows):
+    """oracle.modules.graph_conv (modules.py:194-220) for the output rows `rows` only: the same one-hot concat,
+    x[col] gather, scatter_mean by row * 7 + dir and matmul, on the edges whose row is in `rows` (float64)."""
+    import torch.nn.functional as F
+    from oracle.modules import scatter_mean
+    g = o_doc.graph[d]
+    edge_idx, edge_dir, node_type = g['edge_idx'], g['edge_dir'], g['node_type']
+    x = x.double()
+    if n_node_type > 1:
+        x = torch.cat([x, F.one_hot(node_type, num_classes=n_node_type).double()], dim=1)
+    row, col = edge_idx[0], edge_idx[1]
+    pos = torch.full((x.shape[0],), -1, dtype=torch.int64)
+    pos[rows] = torch.arange(rows.numel())
+    keep = pos[row] >= 0
+    index = pos[row[keep]] * 7 + edge_dir[keep]
+    col_data = scatter_mean(x[col[keep]], index, rows.numel() * 7)
+    return col_data.view(rows.numel(), -1) @ weights.double()
+
+
+def _layers_case():
+    from oracle import modules as OM
+    o_doc = _b8_oracle_tree()
+    d, nt = 8, 7
+    N = int(o_doc.graph[d]['keyd'].shape[0])
+    assert N == N8, N
+    rows = _sample_rows(N)
+    out = {'rows': rows}
+    for name, cin, cout in (('first', 3, 64), ('mid', 64, 64), ('last', 64, 3)):
+        w = C.fill_state_dict([('fb8_%s.weights' % name, (7 * (cin + nt), cout))])['fb8_%s.weights' % name]
+        x = C.rand_input('fb8_x_%s' % name, N, cin)
+        out[name] = _conv_rows(x, o_doc, d, w, nt, rows)
+    x = C.rand_input('fb8_x_gn', N, 64) * 3.0 + 0.5
+    gw, gb = C.fill_state_dict([('fb8_gn.weights', (1, 64)), ('fb8_gn.bias', (1, 64))]).values()
+    y = OM.dual_octree_group_norm(x.double(), o_doc, d, gw.double(), gb.double())
+    out['gn'] = y[rows]
+    out['batch_counts'] = torch.bincount(o_doc.batch_id(d), minlength=8)
+    return out
+
+
+OC.register('feature_b8_layers', _layers_case)
+
+
+def _tree():
+    from octfusion_amd import synthetic
+    from octfusion_amd.dual_octree import DualOctree
+    from octfusion_amd.octree import split2octree_large, split2octree_small
+    oc = split2octree_small(synthetic.shell6_split(8, jitter=True).to(dev()), 6, 4)
+    x6, y6, z6, _ = oc.xyzb(6)
+    return DualOctree(split2octree_large(oc, synthetic.shell8_split_large(x6, y6, z6), 6))
+
+
+def test_feature_b8_layers_vs_float64_oracle_on_sampled_rows():
+    from octfusion_amd import modules as M, ops
+    doc = _tree()
+    d, nt = 8, 7
+    N = doc.csr(d)[2]
+    assert N == N8 and doc.total_num == N8
+    case = OC.get('feature_b8_layers')
+    rows = case['rows'].to(dev())
+    assert torch.equal(torch.bincount(doc.batch_id32(d).long(), minlength=8).cpu(), case['batch_counts'])
+    for name, cin, cout, tol in (('first', 3, 64, 2e-6), ('mid', 64, 64, 2e-5), ('last', 64, 3, 2e-5)):
+        conv = M.GraphConv(cin, cout, 7, 7, nt)
+        conv.load_state_dict({'weights': C.fill_state_dict([('fb8_%s.weights' % name, (7 * (cin + nt), cout))])['fb8_%s.weights' % name]})
+        conv = conv.to(dev())
+        if name == 'last':
+            conv.emit_stats = False
+        x = C.rand_input('fb8_x_%s' % name, N, cin).to(dev())
+        with ops.stats_scope(dev()):
+            y = conv(x, doc, d, split_input=True)
+            st = ops.get_stats(y)
+            e = errors(y[rows], case[name])
+            report(dict(test='feature_b8_layer', layer=name, N=N, cin=cin, cout=cout, **e))
+            assert e['rel_to_max'] < tol, (name, e)
+            assert bool(torch.isfinite(y).all())
+            if st is not None:          # fused GroupNorm statistics of 3.25 M rows against a float64 reduction of the output
+                bid = doc.batch_id32(d).long()
+                want = torch.zeros(8, cout, 2, dtype=torch.float64, device=dev())
+                want[:, :, 0].index_add_(0, bid, y.double())
+                want[:, :, 1].index_add_(0, bid, y.double() ** 2)
+                assert float((st.view(8, cout, 2) - want).abs().max()) <= 1e-6 * float(want.abs().max()), name
+        del x, y
+    assert not ops.sync_error(dev())
+    gn = M.DualOctreeGroupNorm(64)
+    sd = C.fill_state_dict([('fb8_gn.weights', (1, 64)), ('fb8_gn.bias', (1, 64))])
+    gn.load_state_dict({'weights': sd['fb8_gn.weights'], 'bias': sd['fb8_gn.bias']})
+    gn = gn.to(dev())
+    x = (C.rand_input('fb8_x_gn', N, 64) * 3.0 + 0.5).to(dev())
+    y = gn(x, doc, d)
+    e = errors(y[rows], case['gn'])
+    report(dict(test='feature_b8_layer', layer='group_norm', N=N, **e))
+    assert e['rel_to_max'] < 2e-6 and e['elementwise_p999'] < 1e-4, e
+
+
+def test_feature_b8_whole_step_properties():
+    from octfusion_amd import configs, ops, sampler, synthetic
+    from octfusion_amd.graph_unet_union import UNet3DModel
+    doc = _tree()
+    B = 8
+    net = UNet3DModel(**configs.unet_params('obja_uncond', 'feature'))
+    net.load_state_dict(synthetic.random_state_dict(net))
+    net = net.to(dev()).eval()
+    bid = doc.batch_id32(doc.depth).long()
+    x = C.rand_input('fb8_step', doc.total_num, 3).to(dev())
+    # shapes b and b + 4 are the same tree: give them the same input rows
+    counts = torch.bincount(bid, minlength=B).tolist()
+    for b in range(4):
+        assert counts[b] == counts[b + 4]
+        x[bid == b + 4] = x[bid == b]
+    log_snr = sampler.beta_linear_log_snr(torch.full((B,), 0.45)).to(dev())
+    ops.reset_range_words(dev())
+    y = net(unet_type='feature', x=x, doctree=doc, unet_lr=net.unet_hr, timesteps=log_snr, x_self_cond=None, label=None)
+    assert tuple(y.shape) == (N8, 3) and bool(torch.isfinite(y).all())
+    assert not ops.sync_error(dev()) and ops.range_error(dev()) is None
+    sd_y = float(y.std())
+    assert 1e-3 < sd_y < 1e3, sd_y
+    worst = 0.0
+    for b in range(4):
+        a_, b_ = y[bid == b], y[bid == b + 4]
+        worst = max(worst, float((a_ - b_).abs().max()) / float(a_.abs().max()))
+    report(dict(test='feature_b8_step', N=N8, out_std=sd_y, equivariance_rel_to_max=worst))
+    assert worst < 1e-4, worst

@@ -99,7 +99,6 @@ def test_narrow_output_conv(cin, cout, d, nt, bias):
     ntc = nt if nt > 1 else 0
     from octfusion_amd._lib import call, ptr, stream
     out = torch.empty(N, cout, device=dev())
-    tf = doc.type_frac(d, ntc) if ntc else None
-    call('ofx_graphconv_narrow_out', ptr(P), P.stride(0), cout, N, ptr(seg_ptr), ptr(col), ptr(tf), tf.stride(0) if ntc else 0,
-         ntc, ptr(pno.w), cin, ptr(conv.bias) if bias else None, ptr(out), cout, stream())
+    tt = pno.type_term(doc.type_frac(d, ntc) if ntc else None, ntc, N, cin, conv.bias if bias else None)
+    call('ofx_graphconv_narrow_out', ptr(P), P.stride(0), cout, N, ptr(seg_ptr), ptr(col), ptr(tt), ptr(out), cout, stream())
     assert errors(out, ref)['rel_to_max'] < 2e-6

@@ -1,18 +1,26 @@
 #!/bin/bash
-# Copy the evidence of tools/final_runs.sh (merged back under gpurun_out/final/) into the tracked profiles/r04/.
+# Copy the evidence of tools/final_runs.sh (merged back under gpurun_out/final/) into the tracked profiles/r05/.
 set -u
 cd "$(dirname "$0")/.."
-S=gpurun_out/final; D=profiles/r04
+R=r05
+S=gpurun_out/final; D=profiles/$R
 mkdir -p $D
-for w in hr lr hr_cond feature; do [ -s $S/bench_$w.json ] && cp $S/bench_$w.json $D/bench_r04_$w.json; done
-[ -s $S/bench_hr_under_rocprof.json ] && cp $S/bench_hr_under_rocprof.json $D/bench_r04_hr_under_rocprof.json
-[ -s $S/prof/bench_kernel_stats.csv ] && cp $S/prof/bench_kernel_stats.csv $D/bench_r04_hr_kernel_stats.csv
-[ -s $S/prof_gather/gather_kernel_stats.csv ] && cp $S/prof_gather/gather_kernel_stats.csv $D/gather_r04_kernel_stats.csv
-[ -s $S/gather_under_rocprof.json ] && cp $S/gather_under_rocprof.json $D/gather_r04_under_rocprof.json
-for n in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT; do
-  f=$(ls $S/pmc/$n/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $D/pmc_${n}_probe2.csv
+for w in hr lr hr_cond feature; do
+  [ -s $S/bench_$w.json ] && cp $S/bench_$w.json $D/bench_${R}_$w.json
+  [ -s $S/bench_${w}_under_rocprof.json ] && cp $S/bench_${w}_under_rocprof.json $D/bench_${R}_${w}_under_rocprof.json
+  f=$(ls $S/prof_$w/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $D/bench_${R}_${w}_kernel_stats.csv
+  [ -s $S/step_trace_$w.json ] && cp $S/step_trace_$w.json $D/step_trace_$w.json
+  [ -s $S/native_nodes_$w.json ] && cp $S/native_nodes_$w.json $D/native_nodes_$w.json
 done
-for f in pmc_traffic.json generate_probe.json checkpoint_memory.json mfma_rate_probe.txt step_trace_hr.json step_trace_lr.json step_trace_hr_b1.json; do
+f=$(ls $S/prof_gather/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $D/gather_${R}_kernel_stats.csv
+[ -s $S/gather_under_rocprof.json ] && cp $S/gather_under_rocprof.json $D/gather_${R}_under_rocprof.json
+for W in hr feature; do
+  sfx=""; [ $W = feature ] && sfx="_feature"
+  for n in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT; do
+    f=$(ls $S/pmc_$W/$n/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $D/pmc_${n}_probe2$sfx.csv
+  done
+done
+for f in pmc_traffic.json pmc_traffic_feature.json generate_probe.json step_trace_hr_b1.json; do
   [ -s $S/$f ] && cp $S/$f $D/$f
 done
 [ -s gpurun_out/fullwidth_parity.jsonl ] && cp gpurun_out/fullwidth_parity.jsonl $D/fullwidth_parity.jsonl

@@ -27,17 +27,16 @@ OFX_KERNELS = None
 
 
 def ofx_kernel_names():
-    """Kernel symbols of libofx.so (demangled prefixes), so that a device event can be attributed to the library."""
+    """Names of the __global__ functions in octfusion_amd/csrc (the GPU box has no nm / llvm-nm), so that a device event
+    can be attributed to the library."""
     global OFX_KERNELS
     if OFX_KERNELS is None:
+        import glob
         import re
-        import subprocess
-        out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-nm', '-C', '--defined-only', _lib.LIB_PATH], capture_output=True,
-                             text=True).stdout
         names = set()
-        for line in out.splitlines():
-            m = re.search(r'__device_stub__(\w+)', line)
-            if m:
+        for f in glob.glob(os.path.join(ROOT, 'octfusion_amd', 'csrc', '*.h*')):
+            txt = open(f).read()
+            for m in re.finditer(r'__global__\s+(?:void\s+)?(?:__launch_bounds__\([^)]*\)\s*)?(?:void\s+)?(\w+)\s*\(', txt):
                 names.add(m.group(1))
         OFX_KERNELS = names
     return OFX_KERNELS

@@ -1,0 +1,19 @@
+#!/bin/bash
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+OUT=gpurun_out/r05b
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 300 python -m pytest tests/test_gpu_narrow.py -q -x 2>&1 | tail -15
+timeout 200 python tools/native_nodes.py --workload hr --out $OUT/native_nodes_hr.json > $OUT/native_nodes_hr.log 2>&1
+tail -70 $OUT/native_nodes_hr.log
+for v in "OFX_FORK=0" "OFX_FORK=1" "OFX_FORK=2" "OFX_FORK=0 OFX_NARROW_IN=0" "OFX_FORK=0 OFX_NARROW_OUT=0"; do
+  env $v timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2> /dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$v', r['ms_per_step'], r['eager_ms_per_step'])"
+done
+timeout 100 python tools/step_trace.py --workload hr --out $OUT/step_trace_hr.json > /dev/null 2>&1
+python - <<'PY'
+import json
+t=json.load(open('gpurun_out/r05b/step_trace_hr.json'))
+for r in t['last_step']:
+    if 'narrow' in r['call'] or (r['meta'] and r['meta'][3] and r['meta'][3][-1:]==[32]): print(r['call'], round(r['ms']*1e3,1), r['meta'][3])
+PY

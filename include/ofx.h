@@ -526,6 +526,9 @@ int ofx_gather_gemm_f32(const float* x, int64_t ldx, int cin, int ntap, int64_t 
                         const float* zero_row, const float* Wp, int64_t Kp, int cout, const float* bias,
                         const float* res, int64_t ldr, float* out, int64_t ldc, const int32_t* out_rows, void* ws,
                         size_t ws_bytes, int out_mode, void* stream);
+/* A/B knob: 0 keeps sequences of >= 256 tokens on the one-wave-per-32-queries attention kernel (default 1: the keys of a
+ * 32-query tile are split over the four waves of a block). */
+int ofx_set_attention_split(int on);
 int ofx_attention(const float* qkv, int64_t ldq, int batch_size, int T, int heads, int ch,
                   float* out, int64_t ldo, void* stream);
 

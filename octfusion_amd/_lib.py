@@ -93,6 +93,7 @@ _SIGS = {
     'ofx_set_range_words': (c_i, [c_p], True),
     'ofx_get_precision': (c_i, [], False),
     'ofx_gn_apply_rows': (c_i, [], False),
+    'ofx_set_attention_split': (c_i, [c_i], True),
     'ofx_gather_gemm_f32': (c_i, [c_p, c_l, c_i, c_i, c_l, c_l, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_sz, c_i, c_p], True),
     'ofx_graphconv_narrow_in': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_sz, c_p], True),
     'ofx_narrow_out_pack': (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p], True),

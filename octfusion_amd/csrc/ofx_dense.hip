@@ -64,10 +64,18 @@ extern "C" int ofx_grid_conv_table(int mode, int depth_out, int batch_size, int3
 // rescaling, deterministic.
 typedef float f32x16d __attribute__((ext_vector_type(16)));
 
-template <int CH>   // CH = head channels rounded up to 32 (32, 64, 128)
+//
+// SPLIT (round 5, T >= 256): the four waves of a block share ONE tile of 32 queries and split the KEYS four ways
+// (flash-decoding style) instead of owning 32 queries each over all keys.  A (batch, head) then is T / 32 blocks instead
+// of T / 128 -- 512 blocks at batch 8 x 4 heads x 512 tokens, 64 at batch 1 (16 before: the 8^3 level of a one-shape step
+// ran 65 us on 16 CUs) -- and a wave's serial chain of fp32 MFMAs is four times shorter.  Pass 1 ends with a cross-wave
+// combine of (max, sum) through LDS; pass 2's partial outputs are added in wave order (deterministic) through the K
+// stage, which is dead by then.
+template <int CH, bool SPLIT>   // CH = head channels rounded up to 32 (32, 64, 128)
 __global__ void __launch_bounds__(256, 1) attention_mfma_kernel(const float* __restrict__ qkv, int64_t ldq, int T,
                                                                 int heads, int ch, float* __restrict__ out,
                                                                 int64_t ldo) {
+  __shared__ float cmb[4][32][2];
   constexpr int KLD = CH + 4;                     // LDS row pitch (floats): conflict-free b128 reads over rows
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Tp = (T + 31) & ~31;                  // keys padded to whole 32-key tiles
@@ -125,8 +133,8 @@ __global__ void __launch_bounds__(256, 1) attention_mfma_kernel(const float* __r
   }
   __syncthreads();
 
-  const int q0 = blockIdx.y * 128 + wid * 32;      // this wave's 32 queries
-  if (q0 >= T) return;
+  const int q0 = SPLIT ? blockIdx.y * 32 : blockIdx.y * 128 + wid * 32;      // this wave's 32 queries
+  if (q0 >= T) return;                             // (SPLIT: the same for every wave of the block)
   const int qi = q0 + l31;                         // this lane's query (column of S^T)
   const bool qok = qi < T;
   // B operand of S^T = K Q^T: lane (query, h) holds Q[query][h*CH/2 + s], s < CH/2 (k-order permuted)
@@ -161,9 +169,11 @@ __global__ void __launch_bounds__(256, 1) attention_mfma_kernel(const float* __r
     }
   };
 
+  const int kt0 = SPLIT ? (wid * ntile) / 4 : 0, kt1 = SPLIT ? ((wid + 1) * ntile) / 4 : ntile;     // this wave's key tiles
+
   // pass 1: per-query running max and sum of exp
   float mx = -INFINITY, den = 0.f;
-  for (int kt = 0; kt < ntile; ++kt) {
+  for (int kt = kt0; kt < kt1; ++kt) {
     f32x16d st;
     score_tile(kt, st);
     float tm = st[0];
@@ -178,6 +188,20 @@ __global__ void __launch_bounds__(256, 1) attention_mfma_kernel(const float* __r
     den = den * __expf(mx - mn) + ps;
     mx = mn;
   }
+  if (SPLIT) {                                     // (max, sum) of the four key ranges -> the softmax's own
+    if (h == 0) { cmb[wid][l31][0] = mx; cmb[wid][l31][1] = den; }
+    __syncthreads();
+    float gm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) gm = fmaxf(gm, cmb[w][l31][0]);
+    float gd = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float mw = cmb[w][l31][0];
+      gd += mw == -INFINITY ? 0.f : cmb[w][l31][1] * __expf(mw - gm);
+    }
+    mx = gm; den = gd;
+  }
   const float inv = 1.f / den;
 
   // pass 2: O[query, c] += P[query, key] V[key, c]; A = P from registers, B = V rows key(r, h)
@@ -186,7 +210,7 @@ __global__ void __launch_bounds__(256, 1) attention_mfma_kernel(const float* __r
   for (int j = 0; j < CH / 32; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[j][r] = 0.f;
-  for (int kt = 0; kt < ntile; ++kt) {
+  for (int kt = kt0; kt < kt1; ++kt) {
     f32x16d st;
     score_tile(kt, st);
 #pragma unroll
@@ -201,6 +225,22 @@ __global__ void __launch_bounds__(256, 1) attention_mfma_kernel(const float* __r
     }
   }
   // O layout: lane (c = l31, h), reg r -> query q0 + (r&3) + 8(r>>2) + 4h
+  if (SPLIT) {
+    __syncthreads();                               // every wave is done with Ks / Vs: the K stage becomes osum[4][32][CH]
+    float* osum = Ks;
+#pragma unroll
+    for (int j = 0; j < CH / 32; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        osum[(wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * CH + j * 32 + l31] = oacc[j][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * CH; i += 256) {
+      const int q = i / CH, c = i - q * CH;
+      if (q0 + q < T && c < ch)
+        out[(row0 + q0 + q) * ldo + (int64_t)hd * ch + c] = (osum[i] + osum[32 * CH + i]) + (osum[64 * CH + i] + osum[96 * CH + i]);
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < CH / 32; ++j) {
     const int c = j * 32 + l31;
@@ -213,17 +253,27 @@ __global__ void __launch_bounds__(256, 1) attention_mfma_kernel(const float* __r
   }
 }
 
+static int g_attn_split = 1;                     // A/B: ofx_set_attention_split(0) keeps every sequence on the one-wave-per-32-queries kernel
+extern "C" int ofx_set_attention_split(int on) { g_attn_split = on ? 1 : 0; return OFX_OK; }
+
 template <int CH>
 static int launch_attention(const float* qkv, int64_t ldq, int B, int T, int heads, int ch, float* out, int64_t ldo,
                             hipStream_t st) {
   const int Tp = (T + 31) & ~31;
   const size_t lds = (size_t)2 * Tp * (CH + 4) * sizeof(float);
-  if (lds > 160 * 1024) return OFX_EINVAL;
-  static bool attr_set[OFX_MAX_DEVICES] = {};
-  if (!ofx_raise_lds_limit(reinterpret_cast<const void*>(&attention_mfma_kernel<CH>), 160 * 1024, attr_set))
+  if (lds > 160 * 1024 - 2048) return OFX_EINVAL;      // (+ 1 KB of static LDS: the cross-wave combine)
+  static bool attr_set[OFX_MAX_DEVICES] = {}, attr_set_split[OFX_MAX_DEVICES] = {};
+  if (T >= 256 && g_attn_split) {                 // long sequences: keys split over the waves of a block (see the kernel)
+    if (!ofx_raise_lds_limit(reinterpret_cast<const void*>(&attention_mfma_kernel<CH, true>), 160 * 1024 - 2048, attr_set_split))
+      return OFX_ELAUNCH;
+    dim3 grid((unsigned)(B * heads), (unsigned)ofx_cdiv(T, 32));
+    attention_mfma_kernel<CH, true><<<grid, 256, lds, st>>>(qkv, ldq, T, heads, ch, out, ldo);
+    return OFX_OK;
+  }
+  if (!ofx_raise_lds_limit(reinterpret_cast<const void*>(&attention_mfma_kernel<CH, false>), 160 * 1024 - 2048, attr_set))
     return OFX_ELAUNCH;
   dim3 grid((unsigned)(B * heads), (unsigned)ofx_cdiv(T, 128));
-  attention_mfma_kernel<CH><<<grid, 256, lds, st>>>(qkv, ldq, T, heads, ch, out, ldo);
+  attention_mfma_kernel<CH, false><<<grid, 256, lds, st>>>(qkv, ldq, T, heads, ch, out, ldo);
   return OFX_OK;
 }
 

@@ -388,7 +388,10 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
               ssqB.x += v.x * v.x; ssqB.y += v.y * v.y; ssqB.z += v.z * v.z; ssqB.w += v.w * v.w;
             }
           }
-          *reinterpret_cast<float4*>(g.out + m * g.ldc + n) = v;
+          // streaming store (`nt`): the N x Cout output (111 MB at depth 6) is next read by another kernel and would only
+          // push gathered operand lines out of the XCD's 4 MB L2 -- in-run A/B on the hr step, two pairs: 8.483 / 8.470 ->
+          // 8.470 / 8.460 ms, the kernel's roofline fraction 0.4005 / 0.4027 -> 0.4032 / 0.4048
+          __builtin_nontemporal_store(g2_v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<g2_v4f*>(g.out + m * g.ldc + n));
         }
       }
       if (g.stats) {

@@ -649,11 +649,14 @@ def main():
         ops.GRAPHCONV_PROFILE = prof
     dist.barrier()
     torch.cuda.synchronize()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     run_timed(W + 1, K)
+    cpu_issue = time.process_time() - cpu0          # host CPU time to ISSUE the K steps (before waiting for the GPU)
     torch.cuda.synchronize()
     dist.barrier()
     dt_local = time.perf_counter() - t0
+    cpu_total = time.process_time() - cpu0
     ops.GRAPHCONV_PROFILE = None
     dt = dist.max_over_ranks(dt_local, dev)
     rank_ms = dist.gather_floats(1e3 * dt_local / K, dev)
@@ -768,6 +771,9 @@ def main():
                        'parallelism': 'batch-shard x%d, one RCCL weight broadcast (%d bytes)' % (world, wl.bcast_bytes)},
             'shape_steps_per_s': world * batch * K / dt,
             'per_rank_ms_per_step': rank_ms,
+            # what a rank costs the HOST (8 ranks share the node's CPU quota: 16 CPUs on this pool): process CPU time per
+            # step to issue the work, and including the wait for the GPU (torch's synchronize spins)
+            'host_cpu_ms_per_step': {'issue': 1e3 * cpu_issue / K, 'issue_plus_sync_wait': 1e3 * cpu_total / K},
             'weight_broadcast_bytes': wl.bcast_bytes,
             'rccl': rccl_note if world == 1 else 'nccl (RCCL) group of %d ranks' % world,
             'per_shape_setup': {'octree_and_dual_graph_ms': wl.setup_warm_ms, 'octree_and_dual_graph_first_call_ms': wl.setup_ms,

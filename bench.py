@@ -752,7 +752,10 @@ def main():
         narrow = [r_ for r_ in per_layer(prof) if r_['layer'][0].startswith('graph') and min(r_['layer'][2], r_['layer'][3]) <= 8]
         roof['narrow_graphconv_hbm'] = [{'layer': r_['layer'], 'launches': r_['launches'], 'avg_us': r_['avg_us'],
                                          'algorithmic_GBps': r_['GBps'], 'peak': HBM_PEAK_GBS, 'frac': r_['GBps'] / HBM_PEAK_GBS,
-                                         'bound': 'hbm'} for r_ in narrow]
+                                         'bound': 'hbm',
+                                         'note': 'algorithmic bytes = the reference operator\'s (one cin-wide source row per edge + the '
+                                                 'output); the output convolution runs as project-then-aggregate and gathers cout floats '
+                                                 'per edge, so its fraction of the HBM roof on those bytes can exceed 1'} for r_ in narrow]
         roof['all_graphconv_launches'] = graph_only
         roof['gridconv_27tap_launches'] = grid_only
         res = {

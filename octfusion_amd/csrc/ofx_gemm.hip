@@ -875,7 +875,7 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {
 __global__ void pack_bf16x3_kernel(const float* __restrict__ Wp, int64_t Kp, int64_t N, uint16_t* __restrict__ W16,
                                    int h16) {
   const int64_t total = Kp * N;            // one element per (k, n)
-  // per-tensor power-of-two scale of the fp16 halves (trailer behind the 16-bit planes, weight_scale_kernel): the
+  // per-tensor power-of-two scale of the fp16 halves (trailer behind the 16-bit planes, ofx_launch_weight_scale): the
   // epilogues multiply the accumulators by its inverse (GemmArgs::oscale_p; include/ofx.h, range guard)
   const float wscale = h16 ? reinterpret_cast<const float*>(W16 + 2 * total)[1] : 1.f;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -904,8 +904,8 @@ static int g_precision = 3;
 // after ofx_set_precision
 static int pack_bf16x3(const float* Wp, int64_t Kp, int64_t N, hipStream_t st) {
   uint16_t* W16 = reinterpret_cast<uint16_t*>(const_cast<float*>(Wp) + Kp * N);
-  weight_scale_kernel<<<1, 1024, 0, st>>>(Wp, 1, 0, Kp * N, 1, g_precision == 3 ? 1 : 0,
-                                          const_cast<float*>(Wp) + 2 * Kp * N);
+  if (ofx_launch_weight_scale(Wp, 1, 0, Kp * N, 1, g_precision == 3 ? 1 : 0, const_cast<float*>(Wp) + 2 * Kp * N, st))
+    return OFX_ELAUNCH;
   pack_bf16x3_kernel<<<ofx_grid(Kp * N, 256), 256, 0, st>>>(Wp, Kp, N, W16, g_precision == 3 ? 1 : 0);
   return OFX_OK;
 }

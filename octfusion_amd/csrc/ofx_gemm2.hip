@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(256) planes_pack_kernel(const float* __restric
                                                           char* __restrict__ out) {
   // one thread per 16-B piece: (k tile, column, piece)
   const int64_t total = nkt * N * 8;
-  const float wscale = reinterpret_cast<const float*>(out + nkt * N * G2_LINE)[1];     // written by weight_scale_kernel
+  const float wscale = reinterpret_cast<const float*>(out + nkt * N * G2_LINE)[1];     // written by ofx_launch_weight_scale
   const int ch = g2_pairs(mode) ? 32 : 64;
   const int64_t Kf = 7 * (int64_t)cin;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -742,8 +742,9 @@ extern "C" int ofx_pack_weights_planes(const float* W, int64_t sk, int64_t sn, i
     return OFX_EINVAL;
   const int64_t nkt = ofx_planes_packed_ktiles(cin, nt, mode);
   const int ntc = nt > 1 ? nt : 0;
-  weight_scale_kernel<<<1, 1024, 0, ofx_stream(stream)>>>(W, sk, sn, 7 * (int64_t)(cin + ntc), cout, mode != 2 ? 1 : 0,
-                                                          reinterpret_cast<float*>((char*)out + nkt * cout * G2_LINE));
+  if (ofx_launch_weight_scale(W, sk, sn, 7 * (int64_t)(cin + ntc), cout, mode != 2 ? 1 : 0,
+                              reinterpret_cast<float*>((char*)out + nkt * cout * G2_LINE), ofx_stream(stream)))
+    return OFX_ELAUNCH;
   planes_pack_kernel<<<ofx_grid(nkt * cout * 8, 256), 256, 0, ofx_stream(stream)>>>(W, sk, sn, cin, ntc,
                                                                                     cout, nkt, mode, (char*)out);
   OFX_LAUNCH_CHECK();

@@ -41,33 +41,46 @@ struct GemmArgs {
 };
 
 // scale[0] = 1/s, scale[1] = s with s = 2^e such that max|w| * s lies in [2^14, 2^15) (fp16 operands: modes 1 and 3;
-// bf16 pairs have fp32's exponent range: s = 1).  One block; pack time only.
-static __global__ void __launch_bounds__(1024) weight_scale_kernel(const float* __restrict__ W, int64_t sk, int64_t sn, int64_t K,
-                                                            int64_t N, int fp16_operands, float* __restrict__ scale) {
-  __shared__ float red[1024];
+// bf16 pairs have fp32's exponent range: s = 1).  Pack time only.  Grid-wide max|w| by atomicMax on the float's bit
+// pattern (order-preserving for non-negative floats) into scale[0], then one thread turns it into the two scales -- until
+// round 5 this was ONE block walking the whole tensor: up to 1 ms per tensor, 15 ms of a process's first step.
+static __global__ void __launch_bounds__(256) weight_absmax_kernel(const float* __restrict__ W, int64_t sk, int64_t sn, int64_t K,
+                                                            int64_t N, unsigned* __restrict__ acc) {
+  __shared__ float red[256];
   float m = 0.f;
-  for (int64_t t = threadIdx.x; t < K * N; t += 1024) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < K * N; t += (int64_t)gridDim.x * 256) {
     const float a = fabsf(W[(t / N) * sk + (t % N) * sn]);
     if (a <= 3.0e38f) m = fmaxf(m, a);                  // (Inf / NaN weights: left to the arithmetic, not to the scale)
   }
   red[threadIdx.x] = m;
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
+  for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    float s = 1.f;
-    if (fp16_operands && red[0] > 0.f) {
-      int e;
-      frexpf(red[0], &e);                               // red[0] = f * 2^e, f in [0.5, 1)
-      int sh = 15 - e;                                  // max|w| * 2^sh in [2^14, 2^15)
-      sh = sh < -60 ? -60 : (sh > 60 ? 60 : sh);
-      s = ldexpf(1.f, sh);
-    }
-    scale[0] = 1.f / s;
-    scale[1] = s;
+  if (threadIdx.x == 0) atomicMax(acc, __float_as_uint(red[0]));
+}
+static __global__ void weight_scale_finish_kernel(int fp16_operands, float* __restrict__ scale) {
+  const float mx = __uint_as_float(reinterpret_cast<const unsigned*>(scale)[0]);
+  float s = 1.f;
+  if (fp16_operands && mx > 0.f) {
+    int e;
+    frexpf(mx, &e);                                     // mx = f * 2^e, f in [0.5, 1)
+    int sh = 15 - e;                                    // max|w| * 2^sh in [2^14, 2^15)
+    sh = sh < -60 ? -60 : (sh > 60 ? 60 : sh);
+    s = ldexpf(1.f, sh);
   }
+  scale[0] = 1.f / s;
+  scale[1] = s;
+}
+static inline int ofx_launch_weight_scale(const float* W, int64_t sk, int64_t sn, int64_t K, int64_t N, int fp16_operands,
+                                          float* scale, hipStream_t st) {
+  if (hipMemsetAsync(scale, 0, sizeof(float), st) != hipSuccess) return OFX_ELAUNCH;
+  int64_t nb = (K * N + 256 * 16 - 1) / (256 * 16);
+  nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+  weight_absmax_kernel<<<(unsigned)nb, 256, 0, st>>>(W, sk, sn, K, N, reinterpret_cast<unsigned*>(scale));
+  weight_scale_finish_kernel<<<1, 1, 0, st>>>(fp16_operands, scale);
+  return OFX_OK;
 }
 
 

@@ -102,3 +102,37 @@ def test_narrow_output_conv(cin, cout, d, nt, bias):
     tt = pno.type_term(doc.type_frac(d, ntc) if ntc else None, ntc, N, cin, conv.bias if bias else None)
     call('ofx_graphconv_narrow_out', ptr(P), P.stride(0), cout, N, ptr(seg_ptr), ptr(col), ptr(tt), ptr(out), cout, stream())
     assert errors(out, ref)['rel_to_max'] < 2e-6
+
+
+@pytest.mark.parametrize('C_,planes', [(128, 0), (64, 3), (256, 3)])
+def test_downsample_on_a_row_strided_input(C_, planes):
+    """Downsample (modules.py:391-395) when x is a column slice of the skip-concatenation buffer (row pitch != width): the
+    gather-GEMM (ofx_gather_gemm_f32, table 8 r + j) against x.view(-1, 8 C) @ W^T in float64 and against the dense GEMM on
+    a contiguous copy -- with scattered output rows and with the pair-planes epilogue the pooled tensor is written in."""
+    from octfusion_amd import modules as M, ops
+    n = 1000
+    g = torch.Generator().manual_seed(C_)
+    wide = torch.randn(8 * n, C_ + 96, generator=g)
+    x = wide[:, 32:32 + C_]
+    down = M.Downsample(C_)
+    w = C.fill_state_dict([('weights', (C_, C_, 8))])['weights']
+    down.load_state_dict({'weights': w})
+    down = down.to(dev())
+    ref = x.double().reshape(n, 8 * C_) @ w.double().reshape(C_, 8 * C_).t()
+    xg = wide.to(dev())[:, 32:32 + C_]
+    assert xg.stride(0) != C_
+    rows = torch.randperm(n + 50, generator=g)[:n].to(torch.int32).to(dev())
+    out = torch.zeros(n + 50, C_, device=dev())
+    y = down(xg, out=out, out_rows=rows, out_planes=planes)
+    got = ops.planes_merge(_as_planes(out, planes)) if planes else out
+    assert errors(got[rows.long()], ref)['rel_to_max'] < 2e-5
+    out2 = torch.zeros(n + 50, C_, device=dev())
+    down(xg.contiguous(), out=out2, out_rows=rows, out_planes=planes)
+    got2 = ops.planes_merge(_as_planes(out2, planes)) if planes else out2
+    assert float((got - got2).abs().max()) <= 2e-6 * float(got2.abs().max())
+
+
+def _as_planes(t, mode):
+    from octfusion_amd import ops
+    setattr(t, ops.PLANES_ATTR, mode)
+    return t

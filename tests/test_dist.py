@@ -184,11 +184,11 @@ def test_gradient_all_reduce_world2(tmp_path):
 
 
 def test_committed_bench_lines_follow_the_contract():
-    """the four bench lines committed under profiles/r02 carry every field the bench contract names (they are the
-    output of bench.py on the GPU box; this guards the schema against drift)."""
+    """the four bench lines committed under profiles/r02 and profiles/r05 carry every field the bench contract names (they
+    are the output of bench.py on the GPU box; this guards the schema against drift)."""
     import json
-    for wl in ('hr', 'lr', 'hr_cond', 'feature'):
-        line = json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'bench_r02_%s.json' % wl)))
+    for rnd, wl in [(r_, w_) for r_ in ('r02', 'r05') for w_ in ('hr', 'lr', 'hr_cond', 'feature')]:
+        line = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'bench_%s_%s.json' % (rnd, wl))))
         for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                   'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
             assert k in line, (wl, k)

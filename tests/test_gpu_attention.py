@@ -25,7 +25,8 @@ def _ref(qkv, B, T, heads):
     return a.reshape(B * T, C)
 
 
-@pytest.mark.parametrize('B,T,heads,ch', [(8, 512, 4, 32), (1, 512, 4, 16), (3, 288, 2, 24), (2, 256, 4, 32), (4, 64, 4, 64)])
+@pytest.mark.parametrize('B,T,heads,ch', [(8, 512, 4, 32), (1, 512, 4, 16), (3, 288, 2, 24), (2, 256, 4, 32), (2, 256, 2, 64),
+                                          (4, 64, 4, 64)])
 def test_attention_split_keys(B, T, heads, ch):
     from octfusion_amd import _lib, ops
     g = torch.Generator().manual_seed(T * 7 + ch)

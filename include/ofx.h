@@ -451,6 +451,25 @@ int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C, const int
                         int64_t ldo_bytes, const int32_t* seg_ptr, const int32_t* col, const int32_t* multi_seg,
                         int64_t n_multi, void* aux /* optional */, const int32_t* aux_plan /* optional */,
                         int64_t aux_left, void* stream);
+/* ofx_gn_apply_planes_oct (round 6): ofx_gn_apply_planes with aux rows, on the sibling-octet mapping -- the same
+ * outputs (planes of act(GroupNorm(x)) + the consuming GraphConv's aux rows: modules.py:291-326 feeding :194-220).
+ * A thread holds the eight rows of an "octet" (rows 8 o - shift .. 8 o - shift + 7; `shift` pads the coarse-leaf
+ * prefix of the graph depth to a multiple of eight, so the octets of the depth-d part are sibling groups) for its
+ * four channels in registers; an aux row whose sources all lie in one octet is a masked mean of registers.
+ *   oct_ptr   int32 [n_oct + 1], n_oct = ceil((n + shift) / 8): entry range of every octet;
+ *   oct_ent   int32 [n_own][2] (8-B aligned): (aux row id 1..n_multi, 8-bit mask of the octet's rows it averages);
+ *   left_head int32 [n_left][4] (16-B aligned): every other aux row as (aux row id, first slot in left_src, number of
+ *             sources, batch element); always contains the zero row (0, 0, 0, 0); n_own + n_left == n_multi + 1;
+ *   left_src  int32: the source rows of the leftover aux rows, flattened (the CSR segment of each, in order).
+ * Leftover rows are re-normalised from x by extra blocks interleaved with the main blocks (ofx_set_gn_left_place(1):
+ * all behind them, A/B).  mean / rstd are required (ofx_gn_finalize); out must not alias x.  Host-side builder:
+ * octfusion_amd/dual_octree.py DualOctree.oct_plan. */
+int ofx_gn_apply_planes_oct(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id, const float* mean,
+                            const float* rstd, const float* w, const float* bias, int act, int mode, void* out,
+                            int64_t ldo_bytes, int64_t n_multi, void* aux, const int32_t* oct_ptr,
+                            const int32_t* oct_ent, int64_t n_own, int shift, const int32_t* left_head,
+                            const int32_t* left_src, int64_t n_left, void* stream);
+int ofx_set_gn_left_place(int at_end);
 /* rows per main block of ofx_gn_apply_planes: the granularity `aux_plan` is built for (the host-side plan builder,
  * octfusion_amd/dual_octree.py aux_plan, asks instead of assuming). */
 int ofx_gn_apply_rows(void);

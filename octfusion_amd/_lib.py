@@ -111,6 +111,9 @@ _SIGS = {
     'ofx_planes_merge': (c_i, [c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p], True),
     'ofx_gn_apply_planes': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_i, c_i, c_p,
                                   c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p], True),
+    'ofx_gn_apply_planes_oct': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_l, c_l, c_p, c_p, c_p,
+                                      c_l, c_i, c_p, c_p, c_l, c_p], True),
+    'ofx_set_gn_left_place': (c_i, [c_i], True),
     'ofx_planes_packed_ktiles': (c_l, [c_i, c_i, c_i], False),
     'ofx_planes_packed_bytes': (c_l, [c_i, c_i, c_i, c_i], False),
     'ofx_pack_weights_planes': (c_i, [c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_p], True),

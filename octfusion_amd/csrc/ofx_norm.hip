@@ -547,6 +547,214 @@ extern "C" int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C
   return OFX_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// Sibling-octet mapping (round 6): the aux rows for free.
+// An aux row is the mean over one multi-neighbour segment.  On a dual octree 83 % of them (depth 6 / 7 / 8 of the shell
+// trees; 100 % at depth 5) are the four finer neighbours across one face of a coarse leaf: four SIBLINGS, i.e. rows of one
+// aligned group of eight of the depth-d part of the node order (ofx.h: "octet" o = rows 8 o - shift .. 8 o - shift + 7,
+// shift = the number of rows that pad the coarse-leaf prefix to a multiple of eight).  gn_apply_kernel gives a thread the
+// rows rl, rl + RP, ...; an aux row therefore had to wait for the block's stores (barrier), re-read four rows (eight 8-B
+// loads per thread for hi and lo), re-join them -- 2.5 x the memory instructions of a main row: +27...48 % of the launch
+// for 13-17 % more rows (tools/gn_probe.py).  Here a thread owns ALL EIGHT rows of an octet for its four
+// channels: the eight loads are in flight together, the normalised values stay in registers (x is overwritten in place:
+// 32 VGPRs), and an aux row of that octet is a masked sum of registers -- no reload, no LDS, no barrier, no dependent
+// load behind the main rows (the octet's entries (aux row id, 8-bit sibling mask) were requested before them).
+// Entries come from the host plan (dual_octree.DualOctree.oct_plan): oct_ptr [n_oct + 1], oct_ent [n_own] (v, mask).
+// Aux rows whose sources do not sit in one octet (17 %: segments of a leaf two levels up -- 7, 10, 13 or 16 sources from
+// several octets -- and sibling leaves of the coarse prefix that straddle a group boundary) are LEFTOVERS: re-normalised
+// from x by extra blocks behind the main blocks, through a host-flattened source list (left_head / left_src).
+// The value summed for an aux row is the value a reader of the stored planes sees (hi + lo, not the unsplit fp32), so
+// the rows equal the stand-alone pre-pass of the planes GraphConv (planes_multi_mean_kernel) bit for bit.
+template <int MODE>
+__device__ __forceinline__ float4 gn_store_planes(char* orow, int c, const float4& y) {
+  if (MODE == 2 || MODE == 3) {
+    unsigned h0, h1, l0, l1;
+    g2_split2(MODE, y.x, y.y, h0, l0);
+    g2_split2(MODE, y.z, y.w, h1, l1);
+    char* o = orow + (c >> 5) * 128 + (c & 31) * 2;
+    *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(o + 64) = make_uint2(l0, l1);
+    float4 j;
+    g2_join2(MODE, h0, l0, j.x, j.y);
+    g2_join2(MODE, h1, l1, j.z, j.w);
+    return j;
+  } else {
+    const unsigned p0 = g2_pk_f16(y.x, y.y), p1 = g2_pk_f16(y.z, y.w);
+    *reinterpret_cast<uint2*>(orow + c * 2) = make_uint2(p0, p1);
+    return make_float4(g2_f16_lo(p0), g2_f16_hi(p0), g2_f16_lo(p1), g2_f16_hi(p1));
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) gn_apply_oct_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int C,
+                                                           const int32_t* __restrict__ bid,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           int act, char* __restrict__ out, int64_t ldo,
+                                                           int64_t aux_blocks, char* __restrict__ aux,
+                                                           const int32_t* __restrict__ oct_ptr,
+                                                           const int2* __restrict__ oct_ent, int64_t n_oct, int shift,
+                                                           const int4* __restrict__ lhead,
+                                                           const int32_t* __restrict__ lsrc, int64_t n_left,
+                                                           int left_at_end) {
+  const int CT = C >> 2, RP = 256 / CT;
+  const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
+  if (rl >= RP) return;                                   // (256 % (C / 4) != 0: the spare lanes have nothing to do; no barrier below)
+  const int c = cl * 4;
+  // leftover blocks: interleaved with the main blocks in dispatch order as in gn_apply_kernel (block i is the a-th
+  // leftover block if the running share i * A / T steps at i), or all behind them (ofx_set_gn_left_place(1), A/B).
+  // What a leftover row costs is the re-read of its 4 ... 16 source rows (depth 8, C = 128: 0.35 GB on top of the main
+  // pass's 1.66 GB): interleaved, a leftover block runs about when the main blocks of its sources do and finds part of
+  // them in the memory-side cache -- measured 51.4 us (interleaved) vs 58.2 us (behind) at depth 6, C = 128; equal at
+  // depth 8 (tools/gn_probe_oct_parts.py).
+  const int64_t gT = gridDim.x;
+  int64_t a_before;
+  bool is_aux;
+  if (left_at_end) {
+    is_aux = (int64_t)blockIdx.x >= gT - aux_blocks;
+    a_before = is_aux ? (int64_t)blockIdx.x - (gT - aux_blocks) : 0;
+  } else {
+    a_before = aux_blocks > 0 ? ((int64_t)blockIdx.x * aux_blocks) / gT : 0;
+    is_aux = aux_blocks > 0 && (((int64_t)blockIdx.x + 1) * aux_blocks) / gT > a_before;
+  }
+  const int64_t aux_id = a_before, main_id = (int64_t)blockIdx.x - a_before;
+  const int64_t o = main_id * RP + rl;
+  if (!is_aux && o >= n_oct) return;
+
+  int p0 = 0, p1 = 0;
+  float4 v[8];
+  int b[8];
+  if (!is_aux) {
+    // the octet's entry range first (its latency runs under the row loads, and the entries can then be requested
+    // before the rows are waited for), then the eight rows and their batch ids
+    p0 = oct_ptr[o];
+    p1 = oct_ptr[o + 1];
+    const int64_t r0 = 8 * o - shift;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int64_t r = r0 + j;
+      r = r < 0 ? 0 : (r < n ? r : n - 1);                // (rows outside [0, n) are loaded clamped and never stored)
+      b[j] = bid[r];
+      v[j] = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    }
+  }
+  const float4 ww = *reinterpret_cast<const float4*>(w + c);
+  const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+  int cb = -1;
+  float4 m = make_float4(0.f, 0.f, 0.f, 0.f), rs = m;
+  auto norm = [&](int bq, const float4& q) {
+    if (bq != cb) {
+      cb = bq;
+      m = *reinterpret_cast<const float4*>(mean + (int64_t)bq * C + c);
+      rs = *reinterpret_cast<const float4*>(rstd + (int64_t)bq * C + c);
+    }
+    return make_float4(ofx_apply_act((q.x - m.x) * rs.x * ww.x + bb.x, act),
+                       ofx_apply_act((q.y - m.y) * rs.y * ww.y + bb.y, act),
+                       ofx_apply_act((q.z - m.z) * rs.z * ww.z + bb.z, act),
+                       ofx_apply_act((q.w - m.w) * rs.w * ww.w + bb.w, act));
+  };
+  if (is_aux) {
+    // ---- leftover aux rows: mean of the re-normalised source rows (raw x is complete before this launch).  The host
+    // flattened the chain plan -> multi_seg -> seg_ptr -> col into lhead[idx] = (aux row, first source slot, sources,
+    // batch element) + lsrc[]: two dependent loads before the rows instead of four, and the statistics of the batch
+    // element (every source of a segment lies in the batch element of its row) are requested together with the sources.
+    const int64_t idx = aux_id * RP + rl;
+    if (idx >= n_left) return;
+    const int4 hd = lhead[idx];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hd.z > 0) {
+      m = *reinterpret_cast<const float4*>(mean + (int64_t)hd.w * C + c);
+      rs = *reinterpret_cast<const float4*>(rstd + (int64_t)hd.w * C + c);
+      cb = hd.w;
+      const int32_t pa = hd.y, pe = hd.y + hd.z;
+      for (int32_t q0 = pa; q0 < pe; q0 += 4) {
+        int64_t sr[4];
+        float4 xv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sr[k] = lsrc[q0 + k < pe ? q0 + k : pa];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xv[k] = *reinterpret_cast<const float4*>(x + sr[k] * ldx + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 y = norm(hd.w, xv[k]);
+          const float wgt = q0 + k < pe ? 1.f : 0.f;
+          acc.x += wgt * y.x; acc.y += wgt * y.y; acc.z += wgt * y.z; acc.w += wgt * y.w;
+        }
+      }
+      const float inv = 1.f / (float)hd.z;
+      acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    }
+    gn_store_planes<MODE>(aux + (int64_t)hd.x * ldo, c, acc);
+    return;
+  }
+  // ---- main rows of the octet; the first entries are requested now (two dependent loads deep, both L2 hits)
+  constexpr int NPRE = 3;
+  int2 ent[NPRE];
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) ent[k] = p0 + k < p1 ? oct_ent[p0 + k] : make_int2(0, 0);
+  const int64_t r0 = 8 * o - shift;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int64_t r = r0 + j;
+    const float4 y = norm(b[j], v[j]);
+    if (r >= 0 && r < n) v[j] = gn_store_planes<MODE>(out + r * ldo, c, y);
+  }
+  auto entry = [&](const int2 en) {
+    const unsigned msk = (unsigned)en.y;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool on = (msk >> j) & 1u;                    // (a select, not a 0/1 weight: a NaN-poisoned sibling outside the mask stays out)
+      acc.x += on ? v[j].x : 0.f; acc.y += on ? v[j].y : 0.f; acc.z += on ? v[j].z : 0.f; acc.w += on ? v[j].w : 0.f;
+    }
+    const float inv = 1.f / (float)__popc(msk);
+    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    gn_store_planes<MODE>(aux + (int64_t)en.x * ldo, c, acc);
+  };
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k)
+    if (p0 + k < p1) entry(ent[k]);
+  for (int p = p0 + NPRE; p < p1; ++p) entry(oct_ent[p]);
+}
+
+static int g_gn_left_end = 0;              // A/B knob (ofx_set_gn_left_place): 1 = leftover blocks behind the main blocks, 0 = interleaved (default: measured faster)
+extern "C" int ofx_set_gn_left_place(int at_end) { g_gn_left_end = at_end ? 1 : 0; return OFX_OK; }
+
+extern "C" int ofx_gn_apply_planes_oct(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,
+                                       const float* mean, const float* rstd, const float* w, const float* bias, int act,
+                                       int mode, void* out, int64_t ldo_bytes, int64_t n_multi, void* aux,
+                                       const int32_t* oct_ptr, const int32_t* oct_ent, int64_t n_own, int shift,
+                                       const int32_t* left_head, const int32_t* left_src, int64_t n_left,
+                                       void* stream) {
+  const int chunk = g2_pairs(mode) ? 32 : 64;
+  if (mode < 1 || mode > 3 || !x || !batch_id || !mean || !rstd || !w || !bias || !out || !aux || n < 0 || C < chunk ||
+      (C % chunk) || C > 1024 || ldx < C || (ldx & 3) || ldo_bytes < (int64_t)C * (g2_pairs(mode) ? 4 : 2) ||
+      (ldo_bytes & 15) || ((uintptr_t)x & 15) || ((uintptr_t)out & 127) || ((uintptr_t)aux & 127) ||
+      ((uintptr_t)w & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)mean & 15) || ((uintptr_t)rstd & 15) || act < 0 ||
+      act > 2 || (const void*)out == (const void*)x || n_multi < 0 || !oct_ptr || n_own < 0 || n_own > n_multi || (n_own > 0 && (!oct_ent || ((uintptr_t)oct_ent & 7))) || shift < 0 ||
+      shift > 7 || !left_head || ((uintptr_t)left_head & 15) || !left_src || n_left < 1 || n_left > n_multi + 1 ||
+      n_own + n_left != n_multi + 1)
+    return OFX_EINVAL;
+  if (n > 0) {
+    const int RP = 256 / (C >> 2);
+    const int64_t n_oct = ofx_cdiv(n + shift, 8);
+    const int64_t mb = ofx_cdiv(n_oct, RP), ab = ofx_cdiv(n_left, RP);
+    const int grid = (int)(mb + ab);
+    hipStream_t st = ofx_stream(stream);
+#define GN_GO(M_)                                                                                                    \
+  gn_apply_oct_kernel<M_><<<grid, 256, 0, st>>>(x, ldx, n, C, batch_id, mean, rstd, w, bias, act, (char*)out, ldo_bytes, \
+                                                ab, (char*)aux, oct_ptr,                                              \
+                                                reinterpret_cast<const int2*>(oct_ent), n_oct, shift,                 \
+                                                reinterpret_cast<const int4*>(left_head), left_src, n_left, g_gn_left_end)
+    if (mode == 2) GN_GO(2);
+    else if (mode == 3) GN_GO(3);
+    else GN_GO(1);
+#undef GN_GO
+  }
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
 // elementwise activation (shared with ofx_misc entry point)
 __global__ void act_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int act) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)

@@ -123,8 +123,8 @@ class DualOctree:
     def _adopt(self, prev, d, unpool_ok):
         for name in ('_csr', '_nbr', '_ext', '_bid32', '_ntype8', 'batch_id_dict', '_count'):
             getattr(self, name)[d] = getattr(prev, name)[d]
-        for key, v in prev._ext.items():                # aux plans of the adopted depth (keyed ('aux_plan', d, rows))
-            if isinstance(key, tuple) and key[0] == 'aux_plan' and key[1] == d:
+        for key, v in prev._ext.items():                # aux plans of the adopted depth (keyed ('aux_plan', d, rows) / ('oct_plan', d, shift))
+            if isinstance(key, tuple) and key[0] in ('aux_plan', 'oct_plan') and key[1] == d:
                 self._ext[key] = v
         if d in prev._rev:
             self._rev[d] = prev._rev[d]
@@ -258,6 +258,72 @@ class DualOctree:
         left = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), ids[~owned]])
         plan = torch.cat([ptr_, own_ids[order], torch.tensor([left.numel()], device=dev), left]).to(torch.int32)
         self._ext[key] = (plan, int(left.numel()))
+        return self._ext[key]
+
+    def oct_plan(self, d, shift=None):
+        """Aux-row plan of ofx_gn_apply_planes_oct (include/ofx.h) for graph depth d: (plan int32, shift, n_own, n_left,
+        offsets (ptr, ent, left_head, left_src) into plan).
+
+        The rows of a graph depth are [coarse leaves | all nodes of depth d]; the depth-d nodes come in sibling groups of
+        eight.  `shift` pads the leaf prefix to a multiple of eight, so that "octet" o = rows 8 o - shift .. 8 o - shift + 7
+        of the depth-d part IS a sibling group.  An aux row (multi-neighbour segment) whose sources all lie in one octet
+        -- the four finer neighbours across a face of a coarse leaf are siblings: 83 % of the aux rows of the shell trees
+        at depth 6-8, all of them at depth 5 -- is owned by that octet: entry (aux row id, 8-bit mask of the octet's rows).
+        Every other aux row is a leftover: head (aux row id, first slot in the flat source list, sources, batch element).
+        Layout: ptr [n_oct + 1] | pad | ent [n_own][2] | pad | left_head [n_left][4] (the zero row first) | left_src."""
+        if shift is None:
+            shift = (8 - self._leaf_base[d] % 8) % 8
+        key = ('oct_plan', d, shift)
+        if key in self._ext:
+            return self._ext[key]
+        seg_ptr, col, N, E = self.csr(d)
+        _, multi_seg, V = self.ext(d)
+        dev = seg_ptr.device
+        n_oct = (N + shift + 7) // 8
+        ent_off = (n_oct + 1 + 1) & ~1
+        if V == 0:
+            head_off = (ent_off + 3) & ~3
+            plan = torch.zeros(head_off + 4 + 1, dtype=torch.int32, device=dev)
+            self._ext[key] = (plan, shift, 0, 1, (0, ent_off, head_off, head_off + 4))
+            return self._ext[key]
+        ms = multi_seg[:V].long()
+        start, end = seg_ptr[ms].long(), seg_ptr[ms + 1].long()
+        lens = end - start
+        seg_of_edge = torch.repeat_interleave(torch.arange(V, device=dev), lens)
+        edge = torch.repeat_interleave(start - torch.cumsum(lens, 0) + lens, lens) + torch.arange(int(lens.sum()), device=dev)
+        src = col[edge].long() + shift
+        oc = src >> 3
+        lo = torch.full((V,), n_oct, dtype=torch.long, device=dev).scatter_reduce_(0, seg_of_edge, oc, 'amin')
+        hi = torch.full((V,), -1, dtype=torch.long, device=dev).scatter_reduce_(0, seg_of_edge, oc, 'amax')
+        bits = torch.zeros(V, dtype=torch.long, device=dev).scatter_add_(0, seg_of_edge, torch.ones_like(src) << (src & 7))
+        # (the sources of a segment are distinct rows: inside one octet their bits add up to the mask; a repeated source
+        # would carry into the next bit and is sent to the leftovers)
+        pop = torch.zeros_like(bits)
+        for j in range(8):
+            pop += (bits >> j) & 1
+        owned = (lo == hi) & (bits < 256) & (pop == lens)
+        ids = torch.arange(1, V + 1, device=dev)
+        own_ids, own_oct, own_bits = ids[owned], lo[owned], bits[owned]
+        order = torch.argsort(own_oct, stable=True)
+        ptr_ = torch.zeros(n_oct + 1, dtype=torch.long, device=dev)
+        ptr_[1:] = torch.cumsum(torch.bincount(own_oct, minlength=n_oct), 0)
+        ent = torch.stack([own_ids[order], own_bits[order]], dim=1).reshape(-1)
+        n_own = int(own_ids.numel())
+        # leftovers: the CSR segments flattened, so that the kernel's chain is head -> source -> row
+        lv = ~owned
+        l_len = lens[lv]
+        l_start = torch.cumsum(l_len, 0) - l_len
+        l_bid = self.batch_id32(d)[ms[lv] // 7].long()        # (every source of a segment lies in the batch element of its row)
+        head = torch.cat([torch.zeros(1, 4, dtype=torch.long, device=dev),
+                          torch.stack([ids[lv], l_start, l_len, l_bid], dim=1)]).reshape(-1)
+        l_src = col[edge[lv[seg_of_edge]]].long()
+        n_left = int(l_len.numel()) + 1
+        head_off = (ent_off + 2 * n_own + 3) & ~3
+        pad0 = torch.zeros(ent_off - (n_oct + 1), dtype=torch.long, device=dev)
+        pad1 = torch.zeros(head_off - (ent_off + 2 * n_own), dtype=torch.long, device=dev)
+        tail = torch.zeros(1, dtype=torch.long, device=dev)              # (left_src is never empty: slot 0 of the zero row)
+        plan = torch.cat([ptr_, pad0, ent, pad1, head, l_src, tail]).to(torch.int32)
+        self._ext[key] = (plan, shift, n_own, n_left, (0, ent_off, head_off, head_off + 4 * n_left))
         return self._ext[key]
 
     def rev(self, d):

@@ -172,7 +172,12 @@ class DualOctreeGroupNorm(nn.Module):
         if planes:
             seg_ptr, col, _, _ = doctree.csr(depth)
             _, multi_seg, n_multi = doctree.ext(depth)
-            aux_graph = (seg_ptr, col, multi_seg, n_multi, doctree.aux_plan(depth) if ops.AUX_PLAN else None)
+            plan = None
+            if ops.AUX_PLAN == 'oct':
+                plan = doctree.oct_plan(depth)
+            elif ops.AUX_PLAN:
+                plan = doctree.aux_plan(depth)
+            aux_graph = (seg_ptr, col, multi_seg, n_multi, plan)
         y = ops.group_norm(data, doctree.batch_id32(depth), doctree.count(depth), doctree.batch_size,
                            self.weights, self.bias, self.group, self.eps, act, out, stats=stats, planes=planes,
                            aux_graph=aux_graph)

@@ -730,8 +730,14 @@ def graphconv_narrow_out(x, seg_ptr, col, pno, C, type_term=None, out=None):
     assert type_term is None or (type_term.is_contiguous() and tuple(type_term.shape) == (N, cout))
     E = col.numel()
     flops = 2.0 * N * pno.w.shape[0] * cout
-    nbytes = 4.0 * (E * C + N * cout + pno.w.numel()) + 8.0 * E         # the operator's algorithmic bytes, not this path's
-    _meta('graphconv_narrow', flops, nbytes, (N, C, cout, 'narrow_out'))
+    # bytes of the algorithm that RUNS (project-then-aggregate), each array once: the aggregation reads P, the CSR
+    # (7 N segment bounds + E columns) and the cached node-type / bias term and writes the output; the whole operator
+    # (`prof` bracket: projection GEMM + aggregation) also reads x and writes P.  (Until round 5 this line carried the
+    # reference operator's 4 E C bytes, which this path never moves: its "fraction of the HBM roof" read 2.0.)
+    pwid = P.shape[1]
+    agg_bytes = 4.0 * (N * pwid + E + 7 * N + 2 * N * cout)
+    nbytes = agg_bytes + 4.0 * (N * C + N * pwid + pno.w.numel())
+    _meta('graphconv_narrow', flops, agg_bytes, (N, C, cout, 'narrow_out'))
     call('ofx_graphconv_narrow_out', ptr(P), P.stride(0), cout, N, ptr(seg_ptr), ptr(col), ptr(type_term), ptr(out), ldc,
          stream())
     if prof is not None:
@@ -938,7 +944,10 @@ GN_FINALIZE_LAUNCH = False
 # (round 4, same box, same run: lr stage 1.052 -> 1.015 ms per step, hr 8.80 -> 8.74 with 2048 = the 16^3 level)
 GN_ROWS_TWO_KERNELS = int(os.environ.get('OFX_GN_ROWS_TWO_KERNELS', '2048'))
 GN_FUSE_AUX_FINALIZE = os.environ.get('OFX_GN_FUSE_AUX_FINALIZE', '0') == '1'
-AUX_PLAN = os.environ.get('OFX_AUX_PLAN', '1') == '1'                 # aux rows written by the main block that holds their sources (A/B: False = separate aux blocks)
+# who writes the aux rows of a GroupNorm launch: 'oct' (default, round 6) = the thread that holds the sibling octet of their
+# sources in registers (ofx_gn_apply_planes_oct); 'block' (round 4) = the 64-row block that holds their sources, from its own
+# output; '' / '0' = separate aux blocks (round 3).  A/B: OFX_AUX_PLAN=oct|block|0
+AUX_PLAN = {'1': 'oct', '0': ''}.get(os.environ.get('OFX_AUX_PLAN', 'oct'), os.environ.get('OFX_AUX_PLAN', 'oct'))
 
 
 def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, act=None, out=None,
@@ -1003,10 +1012,23 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         n_multi = n_left = 0
         if aux_graph is not None:
             seg_ptr, col, multi_seg, n_multi = aux_graph[:4]
+            oct_plan = None
             if len(aux_graph) > 4 and aux_graph[4] is not None and AUX_PLAN:
-                plan, n_left = aux_graph[4]          # (int32 plan, leftover count): dual_octree.DualOctree.aux_plan
+                if len(aux_graph[4]) == 5:
+                    oct_plan = aux_graph[4]          # dual_octree.DualOctree.oct_plan
+                else:
+                    plan, n_left = aux_graph[4]      # (int32 plan, leftover count): dual_octree.DualOctree.aux_plan
             aux = torch.empty((n_multi + 1) * ldo, dtype=torch.uint8, device=dev)
         _meta('gn_apply', 0, 8.0 * n * C + (n_multi + 1) * float(ldo), (n, C, 'planes+aux' if aux is not None else 'planes'))
+        if aux is not None and oct_plan is not None and mean is not None:
+            op, shift, n_own, n_left, (o_ptr, o_ent, o_head, o_src) = oct_plan
+            base = op.data_ptr()
+            call('ofx_gn_apply_planes_oct', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(w), ptr(b), ACT[act],
+                 planes, ptr(out), ldo, n_multi, ptr(aux), base + 4 * o_ptr, base + 4 * o_ent, n_own, shift,
+                 base + 4 * o_head, base + 4 * o_src, n_left, stream())
+            setattr(out, PLANES_ATTR, planes)
+            setattr(out, AUX_ATTR, aux)
+            return out
         call('ofx_gn_apply_planes', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(sums), ptr(count), groups, eps,
              count_eps, ptr(w), ptr(b), ACT[act], planes, ptr(out), ldo, ptr(seg_ptr), ptr(col), ptr(multi_seg), n_multi,
              ptr(aux), ptr(plan), n_left, stream())

@@ -4,9 +4,12 @@ bench's own spot check.  Reference: models/networks/diffusion_networks/graph_une
 middle (octfusion_model_union_3t.py:152-214), configs/octfusion_obja_uncond.yaml:11-24.
 
 A whole fp64 oracle step at this size is minutes of CPU and > 60 GB, so:
-  * single layers against the oracle in FLOAT64 on a seeded sample of 8 192 output rows (the oracle's own
+  * single layers against the oracle in FLOAT64 on a seeded sample of 8 192 output rows PLUS the rows on both sides of
+    every stream-K share boundary and every XCD-group boundary of the persistent launch's plan (`ofx_gconv3_plan`: the
+    places where a tile changes hands between blocks / L2s) -- ~10.7 k rows, stored VERBATIM
+    (`oracle_cache.Full`; the round-5 fixture re-sketched them down to 318 rows).  The oracle's own
     scatter_mean / one-hot / matmul sequence of modules.py:194-220 restricted to the edges of those rows; fixture
-    `feature_b8_layers`, computed once on the CPU by tests/golden/make_oracle_cache.py): the network's first GraphConv
+    `feature_b8_layers`, computed once on the CPU by tests/golden/make_oracle_cache.py: the network's first GraphConv
     (3 -> 64 at depth 8, the gather kernel), a 64 -> 64 depth-8 GraphConv (planes kernel, persistent launch: 12 690 row
     tiles), the last one (64 -> 3, project-then-aggregate), and a DualOctreeGroupNorm over all 3.25 M rows (fp64 statistics
     of the whole tensor, sampled rows compared);
@@ -28,10 +31,38 @@ N8 = 3248400
 SAMPLE = 8192
 
 
+def _plan_boundary_rows(n, cin=64, cout=64, nt=7, wm=4, ni=1, cus=256):
+    """Rows next to the places where the persistent planes GraphConv (csrc/ofx_gemm3.hip) hands work from one block /
+    XCD to the next, for the 64 -> 64 depth-8 layer: the first and last row of every tile that starts an XCD group
+    (32 consecutive tiles of a whole-tile round share one L2) or holds a stream-K share boundary, and the rows just
+    outside it.  Host arithmetic only (ofx_gconv3_plan: no device)."""
+    import ctypes
+    from octfusion_amd import _lib
+    L = _lib.lib()
+    nkt = int(L.ofx_planes_packed_ktiles(cin, nt, 3))
+    buf = (ctypes.c_int32 * (5 + 2 * cus + 2))()
+    G = L.ofx_gconv3_plan(n, cout, nkt, wm, ni, cus, buf, len(buf))
+    assert G > 0
+    rounds = buf[4]
+    bm = wm * 64
+    tiles = set()
+    for r in range(rounds):
+        for x in range(8):
+            tiles.add(r * G + x * (G // 8))
+    for b in range(G + 1):
+        tiles.add(rounds * G + buf[5 + b] // nkt)
+    rows = []
+    for t in tiles:
+        for r in (t * bm - 1, t * bm, t * bm + bm - 1, t * bm + bm):
+            if 0 <= r < n:
+                rows.append(r)
+    return torch.tensor(sorted(set(rows)), dtype=torch.int64)
+
+
 def _sample_rows(n):
     g = torch.Generator().manual_seed(20250805)
     idx = torch.randperm(n, generator=g)[:SAMPLE - 64]
-    return torch.unique(torch.cat([idx, torch.arange(32), torch.arange(n - 32, n)]))
+    return torch.unique(torch.cat([idx, torch.arange(32), torch.arange(n - 32, n), _plan_boundary_rows(n)]))
 
 
 def _b8_oracle_tree():
@@ -75,11 +106,11 @@ def _layers_case():
     for name, cin, cout in (('first', 3, 64), ('mid', 64, 64), ('last', 64, 3)):
         w = C.fill_state_dict([('fb8_%s.weights' % name, (7 * (cin + nt), cout))])['fb8_%s.weights' % name]
         x = C.rand_input('fb8_x_%s' % name, N, cin)
-        out[name] = _conv_rows(x, o_doc, d, w, nt, rows)
+        out[name] = OC.Full(_conv_rows(x, o_doc, d, w, nt, rows))
     x = C.rand_input('fb8_x_gn', N, 64) * 3.0 + 0.5
     gw, gb = C.fill_state_dict([('fb8_gn.weights', (1, 64)), ('fb8_gn.bias', (1, 64))]).values()
     y = OM.dual_octree_group_norm(x.double(), o_doc, d, gw.double(), gb.double())
-    out['gn'] = y[rows]
+    out['gn'] = OC.Full(y[rows])
     out['batch_counts'] = torch.bincount(o_doc.batch_id(d), minlength=8)
     return out
 
@@ -104,6 +135,10 @@ def test_feature_b8_layers_vs_float64_oracle_on_sampled_rows():
     assert N == N8 and doc.total_num == N8
     case = OC.get('feature_b8_layers')
     rows = case['rows'].to(dev())
+    assert rows.numel() >= SAMPLE and tuple(case['mid'].shape) == (rows.numel(), 64)      # stored verbatim, not sketched
+    # the sample holds the boundary rows of the plan the library computes NOW (a changed geometry / schedule must be
+    # followed by `python tests/golden/make_oracle_cache.py --only feature_b8`)
+    assert bool(torch.isin(_plan_boundary_rows(N), case['rows']).all()), 'launch plan changed: regenerate the fixture'
     assert torch.equal(torch.bincount(doc.batch_id32(d).long(), minlength=8).cpu(), case['batch_counts'])
     for name, cin, cout, tol in (('first', 3, 64, 2e-6), ('mid', 64, 64, 2e-5), ('last', 64, 3, 2e-5)):
         conv = M.GraphConv(cin, cout, 7, 7, nt)
@@ -116,7 +151,7 @@ def test_feature_b8_layers_vs_float64_oracle_on_sampled_rows():
             y = conv(x, doc, d, split_input=True)
             st = ops.get_stats(y)
             e = errors(y[rows], case[name])
-            report(dict(test='feature_b8_layer', layer=name, N=N, cin=cin, cout=cout, **e))
+            report(dict(test='feature_b8_layer', layer=name, N=N, cin=cin, cout=cout, sampled_rows=int(rows.numel()), **e))
             assert e['rel_to_max'] < tol, (name, e)
             assert bool(torch.isfinite(y).all())
             if st is not None:          # fused GroupNorm statistics of 3.25 M rows against a float64 reduction of the output
@@ -134,7 +169,7 @@ def test_feature_b8_layers_vs_float64_oracle_on_sampled_rows():
     x = (C.rand_input('fb8_x_gn', N, 64) * 3.0 + 0.5).to(dev())
     y = gn(x, doc, d)
     e = errors(y[rows], case['gn'])
-    report(dict(test='feature_b8_layer', layer='group_norm', N=N, **e))
+    report(dict(test='feature_b8_layer', layer='group_norm', N=N, sampled_rows=int(rows.numel()), **e))
     assert e['rel_to_max'] < 2e-6 and e['elementwise_p999'] < 1e-4, e
 
 

@@ -14,6 +14,8 @@ def _stub(seg_ptr, col, multi_seg, N):
     s.csr = lambda d: (seg_ptr, col, N, int(col.numel()))
     s.ext = lambda d: (None, multi_seg, int(multi_seg.numel()))
     s.aux_plan = lambda d, rows_per_block=64: DualOctree.aux_plan(s, d, rows_per_block)
+    s.oct_plan = lambda d, shift=0: DualOctree.oct_plan(s, d, shift)
+    s.batch_id32 = lambda d: (torch.arange(N, dtype=torch.int32) * 3) // max(N, 1)
     return s
 
 
@@ -66,6 +68,50 @@ def test_aux_plan_partitions_the_aux_rows_by_owner_block():
     col = torch.zeros(70, dtype=torch.int32)
     plan, n_left = _stub(seg_ptr, col, torch.zeros(0, dtype=torch.int32), 10).aux_plan(4)
     assert n_left == 1 and plan.tolist() == [0, 0, 1, 0]
+
+
+def test_oct_plan_gives_every_aux_row_to_one_octet_or_to_the_leftovers():
+    """dual_octree.DualOctree.oct_plan (include/ofx.h ofx_gn_apply_planes_oct): an entry (v, mask) of octet o means that
+    the sources of aux row v are exactly the rows 8 o - shift + j of the set bits j; every other aux row is a leftover
+    whose head points at its CSR segment, flattened."""
+    for N, seed, shift in ((1, 0, 0), (70, 1, 0), (70, 1, 3), (700, 2, 5), (1000, 3, 7), (1003, 4, 2)):
+        seg_ptr, col, multi_seg = _random_graph(N, seed)
+        V = int(multi_seg.numel())
+        if V == 0:
+            continue
+        st = _stub(seg_ptr, col, multi_seg, N)
+        plan, sh, n_own, n_left, (o_ptr, o_ent, o_head, o_src) = st.oct_plan(5, shift)
+        assert sh == shift and o_ent % 2 == 0 and o_head % 4 == 0 and n_own + n_left == V + 1
+        plan = plan.tolist()
+        n_oct = (N + shift + 7) // 8
+        ptr = plan[o_ptr:o_ptr + n_oct + 1]
+        assert ptr[0] == 0 and ptr[-1] == n_own and all(a <= b for a, b in zip(ptr, ptr[1:]))
+        ent = plan[o_ent:o_ent + 2 * n_own]
+        head = [plan[o_head + 4 * i:o_head + 4 * i + 4] for i in range(n_left)]
+        assert o_src == o_head + 4 * n_left and head[0] == [0, 0, 0, 0]
+        assert sorted(ent[0::2] + [h[0] for h in head]) == list(range(V + 1))     # every aux row exactly once
+        for o in range(n_oct):
+            for i in range(ptr[o], ptr[o + 1]):
+                v, mask = ent[2 * i], ent[2 * i + 1]
+                s = int(multi_seg[v - 1])
+                srcs = col[int(seg_ptr[s]):int(seg_ptr[s + 1])].tolist()
+                assert 0 < mask < 256
+                assert sorted(srcs) == [8 * o - shift + j for j in range(8) if mask >> j & 1], (o, v, mask, srcs)
+        bid = st.batch_id32(5).tolist()
+        nxt = 0
+        for v, start, cnt, b in head[1:]:
+            s = int(multi_seg[v - 1])
+            srcs = col[int(seg_ptr[s]):int(seg_ptr[s + 1])].tolist()
+            assert start == nxt and cnt == len(srcs) and plan[o_src + start:o_src + start + cnt] == srcs
+            assert b == bid[s // 7]
+            assert len({(r + shift) // 8 for r in srcs}) > 1 or len(set(srcs)) < len(srcs)
+            nxt += cnt
+        assert len(plan) == o_src + nxt + 1
+    # no multi-neighbour segment: only the zero row, as a leftover
+    seg_ptr = torch.arange(0, 7 * 10 + 1, dtype=torch.int32)
+    col = torch.zeros(70, dtype=torch.int32)
+    plan, sh, n_own, n_left, (o_ptr, o_ent, o_head, o_src) = _stub(seg_ptr, col, torch.zeros(0, dtype=torch.int32), 10).oct_plan(4, 0)
+    assert n_own == 0 and n_left == 1 and not plan.any() and len(plan) > o_src
 
 
 def test_cpu_baseline_sizes_itself_inside_the_cgroup_quota(tmp_path, monkeypatch):

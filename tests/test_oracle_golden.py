@@ -464,3 +464,56 @@ def test_points_octree_oracle():
     ne = oc.nempty_mask(depth)
     torch.testing.assert_close(feat[ne, :3].norm(dim=1), torch.ones(int(ne.sum())), rtol=1e-5, atol=1e-5)
     assert float(feat[~ne].abs().max()) == 0.0 and float(feat[:, 3].abs().max()) <= 0.867
+
+
+def test_sketch_detects_a_localised_error():
+    """tests/golden/oracle_cache.py: the block projections of a Sketch see ONE wrong row and one wrong 64 x 32 tile
+    anywhere in a tensor whose row sample holds 0.3 % of the rows ('a handful of wrong rows at a
+    tile / share / XCD boundary passes'), at the tolerances the GPU tests use; rounding-level noise stays below them."""
+    import oracle_cache as OC
+    g = torch.Generator().manual_seed(5)
+    t = torch.randn(100_000, 128, generator=g)
+    sk = OC.unpack(OC.pack('unit', t))
+    assert isinstance(sk, OC.Sketch) and sk.idx.numel() < 400 and tuple(sk.proj.shape) == ((100_000 + 63) // 64, OC.NPROJ)
+    scale = float(t.abs().max())
+    y = t + 1e-6 * scale * torch.randn(t.shape, generator=g)           # fp16x3-level rounding noise
+    e0 = OC.errors(y, sk)
+    assert e0['rel_to_max'] < 1e-5 and e0['rows_covered'] == 100_000, e0
+    row = 51_234
+    assert row not in set(sk.idx.tolist())
+    y1 = y.clone()
+    y1[row] += 2e-4 * scale                                             # one row, every element off by 2e-4 of the range
+    e1 = OC.errors(y1, sk)
+    assert e1['proj_rel'] > 2e-5 and e1['rel_to_max'] > 2e-5, e1        # (the per-layer sweep's bar is 2e-5)
+    y2 = y.clone()
+    y2[64 * 700:64 * 701, 32:64] += 1e-4 * scale                        # one 64-row x 32-column sub-tile
+    e2 = OC.errors(y2, sk)
+    assert e2['rel_to_max'] > 2e-5, e2
+    y3 = y.clone()
+    y3[99_990, 5] = 0.0                                                 # one element lost (e.g. a clamped column)
+    assert OC.errors(y3, sk)['rel_to_max'] > 1e-4 or abs(float(t[99_990, 5])) < 1e-3 * scale
+    # Full / Rows wrappers
+    f = OC.unpack(OC.pack('unit_full', OC.Full(t)))
+    assert torch.is_tensor(f) and torch.equal(f, t)
+    sr = OC.unpack(OC.pack('unit_rows', OC.Rows(t, torch.tensor([row, 70_000]))))
+    assert {row, 70_000} <= set(sr.idx.tolist())
+
+
+def test_oracle_cache_fixtures_are_current():
+    """Every committed tests/golden/oracle_cache/*.pt carries the digest of the tree: oracle/*.py, the input builders,
+    oracle_cache.py AND the test module that registers the case (an edited oracle invocation must invalidate
+    its fixture).  The GPU tests assert the same when they read a fixture; this is the CPU-side check of all of them."""
+    import importlib
+    import os
+    import oracle_cache as OC
+    import make_oracle_cache as MK
+    for m in MK.MODULES:
+        importlib.import_module(m)
+    files = sorted(f for f in os.listdir(OC.DIR) if f.endswith('.pt'))
+    assert len(files) >= 50
+    for f in files:
+        name = f[:-3]
+        assert name in OC.REGISTRY, 'fixture %s has no registered case' % f
+        rec = torch.load(os.path.join(OC.DIR, f), weights_only=False)
+        assert rec['digest'] == OC.case_digest(name), (f, rec['digest'], OC.case_digest(name))
+    assert set(OC.REGISTRY) == {f[:-3] for f in files}, 'cases without a fixture: %s' % sorted(set(OC.REGISTRY) - {f[:-3] for f in files})

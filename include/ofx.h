@@ -462,10 +462,12 @@ int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C, const int
  *             sources, batch element); always contains the zero row (0, 0, 0, 0); n_own + n_left == n_multi + 1;
  *   left_src  int32: the source rows of the leftover aux rows, flattened (the CSR segment of each, in order).
  * Leftover rows are re-normalised from x by extra blocks interleaved with the main blocks (ofx_set_gn_left_place(1):
- * all behind them, A/B).  mean / rstd are required (ofx_gn_finalize); out must not alias x.  Host-side builder:
+ * all behind them, A/B).  mean / rstd from ofx_gn_finalize, or both NULL with (sums, count, groups, eps, count_eps):
+ * finalised per block on the fly, as in ofx_gn_apply.  out must not alias x.  Host-side builder:
  * octfusion_amd/dual_octree.py DualOctree.oct_plan. */
 int ofx_gn_apply_planes_oct(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id, const float* mean,
-                            const float* rstd, const float* w, const float* bias, int act, int mode, void* out,
+                            const float* rstd, const double* sums, const float* count, int groups, float eps,
+                            float count_eps, const float* w, const float* bias, int act, int mode, void* out,
                             int64_t ldo_bytes, int64_t n_multi, void* aux, const int32_t* oct_ptr,
                             const int32_t* oct_ent, int64_t n_own, int shift, const int32_t* left_head,
                             const int32_t* left_src, int64_t n_left, void* stream);
@@ -488,6 +490,9 @@ int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int cin, int64_t
  * per block; 2: persistent with pure stream-K (no whole-tile rounds); 3: as 1 with share boundaries snapped towards the
  * tile boundary instead of to the nearest legal cut -- A/B knobs, same values */
 int ofx_set_gconv_persistent(int on);
+/* A/B knob of the persistent launch's tile order: 1 = every XCD walks one contiguous range of tiles over the whole
+ * launch (csrc/ofx_gemm3.hip, Gemm3Args::xcd_contig), 0 = the XCDs interleave inside every whole-tile round. */
+int ofx_set_gconv_xcd_contig(int on);
 /* The schedule ofx_graphconv_fwd_planes' persistent launch would use for n_rows x cout outputs and nkt k-steps per tile
  * (host only, no device work; cus > 0: plan for that many compute units): out[0..4] = blocks G, q, rem, region units U,
  * whole-tile rounds; out[5 .. 5 + G] = share boundaries of the stream-K region (k-step units, bound(0) = 0,

@@ -111,8 +111,8 @@ _SIGS = {
     'ofx_planes_merge': (c_i, [c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p], True),
     'ofx_gn_apply_planes': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_i, c_i, c_p,
                                   c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p], True),
-    'ofx_gn_apply_planes_oct': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_l, c_l, c_p, c_p, c_p,
-                                      c_l, c_i, c_p, c_p, c_l, c_p], True),
+    'ofx_gn_apply_planes_oct': (c_i, [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p, c_i, c_i, c_p,
+                                      c_l, c_l, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_l, c_p], True),
     'ofx_set_gn_left_place': (c_i, [c_i], True),
     'ofx_planes_packed_ktiles': (c_l, [c_i, c_i, c_i], False),
     'ofx_planes_packed_bytes': (c_l, [c_i, c_i, c_i, c_i], False),
@@ -121,6 +121,7 @@ _SIGS = {
                                        c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_sz, c_p, c_sz, c_i, c_i,
                                        c_p], True),
     'ofx_set_gconv_persistent': (c_i, [c_i], True),
+    'ofx_set_gconv_xcd_contig': (c_i, [c_i], True),
     'ofx_gconv3_plan': (c_i, [c_l, c_i, c_i, c_i, c_i, c_i, c_p, c_l], False),
     'ofx_set_gconv2_variant': (c_i, [c_i], True),
     'ofx_set_gconv2_debug': (c_i, [c_p], True),

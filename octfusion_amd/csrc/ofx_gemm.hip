@@ -907,7 +907,7 @@ static int pack_bf16x3(const float* Wp, int64_t Kp, int64_t N, hipStream_t st) {
   if (ofx_launch_weight_scale(Wp, 1, 0, Kp * N, 1, g_precision == 3 ? 1 : 0, const_cast<float*>(Wp) + 2 * Kp * N, st))
     return OFX_ELAUNCH;
   pack_bf16x3_kernel<<<ofx_grid(Kp * N, 256), 256, 0, st>>>(Wp, Kp, N, W16, g_precision == 3 ? 1 : 0);
-  return OFX_OK;
+  return hipGetLastError() == hipSuccess ? OFX_OK : OFX_ELAUNCH;
 }
 
 // 3 (default): fp16x3 -- operands as fp16 hi + lo pairs, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate:
@@ -1233,7 +1233,7 @@ extern "C" int ofx_pack_weights(const float* W, int64_t sk, int64_t sn, int64_t 
   }
   if (((uintptr_t)Wp & 15) != 0) return OFX_EINVAL;
   pack_weights_kernel<<<ofx_grid((Kp / 4) * N, 256), 256, 0, ofx_stream(stream)>>>(W, sk, sn, K, N, cin, nt, Wp, Kp);
-  pack_bf16x3(Wp, Kp, N, ofx_stream(stream));
+  if (int rc = pack_bf16x3(Wp, Kp, N, ofx_stream(stream))) return rc;
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
@@ -1264,7 +1264,7 @@ extern "C" int ofx_pack_conv3d(const float* W, int cin, int cout, float* Wp, voi
   if (!W || !Wp || cin < 1 || cout < 1 || ((uintptr_t)Wp & 15)) return OFX_EINVAL;
   const int64_t Kp = ofx_conv3d_packed_k(cin);
   pack_conv3d_kernel<<<ofx_grid((Kp / 4) * cout, 256), 256, 0, ofx_stream(stream)>>>(W, cin, cout, Wp, Kp);
-  pack_bf16x3(Wp, Kp, cout, ofx_stream(stream));
+  if (int rc = pack_bf16x3(Wp, Kp, cout, ofx_stream(stream))) return rc;
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }

@@ -62,6 +62,12 @@ struct Gemm3Args {
   int early;                   // every share spans >= one tile (a tile is cut at most once, and its second piece is
                                // published before the finisher STARTS its own): the finisher starts from that piece
                                // instead of adding it at the end
+  int xcd_contig;              // 1: every XCD walks ONE contiguous range of tiles over the whole launch (its rounds and its
+                               // part of the region): consecutive rounds of an XCD are neighbours in Morton order, so
+                               // the halo rows and the coarse-leaf / aux rows one round pulled into that XCD's L2 are
+                               // what the next round gathers again.  0: round r of XCD x = tiles r * G + x * G / 8 ...
+                               // (the XCDs interleave inside every round; rounds are G tiles apart) -- A/B
+  unsigned rt;                 // tiles of the stream-K region (U / nkt)
 };
 
 __device__ __forceinline__ void g3_ds_write32(unsigned addr, unsigned v) {
@@ -377,7 +383,26 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
   unsigned t_cur = in_region ? dp_tiles + u / (unsigned)nkt : (unsigned)lb;
   int k0 = in_region ? (int)(u % (unsigned)nkt) : 0;
   if (!in_region) dp_r = 1;
-  int tm = (int)(t_cur / (unsigned)ntn), tn = (int)t_cur - tm * ntn;
+  // logical tile index (what the schedule above hands out) -> tile of the layer.  xcd_contig: XCD x owns the tiles
+  // [cb(x), cb(x + 1)), cb(x) = x * R * G/8 + floor(x * RT / 8): first its R whole-tile rounds of G/8 tiles, then its
+  // eighth of the region (the region's units are cut into G equal shares in logical order, so the shares of XCD x's
+  // blocks fall into the x-th eighth of the region's tiles up to a tile at either end) -- a bijection on [0, T).
+  // (256-row geometry only: the layers with whole-tile rounds; the 128-row instantiations have no register to spare)
+  const bool contig = WM == 4 && A.xcd_contig != 0 && A.rt >= 8u;
+  auto phys = [&](unsigned s) -> unsigned {
+    if (WM != 4 || !contig) return s;
+    const unsigned G8 = (unsigned)G >> 3, RT = A.rt, R = (unsigned)dp_rounds;
+    if (s < dp_tiles) {
+      const unsigned r = s / (unsigned)G, l = s - r * (unsigned)G, x = l / G8, j = l - x * G8;
+      return x * R * G8 + (x * RT >> 3) + r * G8 + j;
+    }
+    const unsigned q = s - dp_tiles;
+    unsigned x = (8u * q + 7u) / RT;              // the largest x with floor(x * RT / 8) <= q
+    x = x > 7u ? 7u : x;
+    return x * R * G8 + (x * RT >> 3) + R * G8 + (q - (x * RT >> 3));
+  };
+  const unsigned t_phys0 = phys(t_cur);
+  int tm = (int)(t_phys0 / (unsigned)ntn), tn = (int)t_phys0 - tm * ntn;
   int64_t m0 = a.row0 + (int64_t)tm * G2_BM, n0 = (int64_t)tn * G2_BN;
   raw_request(m0);
   g2_wait_barrier<0>();
@@ -438,7 +463,8 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
       t_nxt = (unsigned)dp_r * (unsigned)G + (unsigned)lb;
     }
     const int len = k1 - k0;
-    const int tm_n = (int)(t_nxt / (unsigned)ntn), tn_n = (int)t_nxt - tm_n * ntn;
+    const unsigned t_nxt_p = phys(t_nxt);
+    const int tm_n = (int)(t_nxt_p / (unsigned)ntn), tn_n = (int)t_nxt_p - tm_n * ntn;
     const int64_t m0_n = a.row0 + (int64_t)tm_n * G2_BM, n0_n = (int64_t)tn_n * G2_BN;
     const bool new_rows = has_next && tm_n != tm;
     const bool finisher = k0 == 0;                                       // (always, outside the region)
@@ -731,6 +757,7 @@ static int g3_cus() {                  // compute units of the current device (c
 // Launch plan: wm (2 / 4), ni (1 / 2) -> blocks G, units per block.
 struct G3Plan { int G; unsigned q, rem, U; int dp_rounds; size_t part_bytes; };
 static int g3_snap = 1;        // 1: nearest legal cut position; 0: towards the tile boundary (A/B, ofx_set_gconv_persistent(3))
+static int g3_xcd_contig = 0;  // tile order: 1 = one contiguous tile range per XCD (Gemm3Args::xcd_contig), A/B: ofx_set_gconv_xcd_contig
 static int g3_hybrid = 1;      // 1: whole-tile rounds + stream-K region; 0: pure stream-K (A/B, ofx_set_gconv_persistent(2))
 static bool g3_plan(int64_t M, int cout, int nkt, int wm, int ni, G3Plan& p, int cus = 0) {
   if (cus <= 0) cus = g3_cus();
@@ -761,6 +788,7 @@ static bool g3_plan(int64_t M, int cout, int nkt, int wm, int ni, G3Plan& p, int
 }
 
 void ofx_gconv3_set_hybrid(int on) { g3_hybrid = on ? 1 : 0; }
+extern "C" int ofx_set_gconv_xcd_contig(int on) { g3_xcd_contig = on ? 1 : 0; return OFX_OK; }
 void ofx_gconv3_set_snap(int near) { g3_snap = near ? 1 : 0; }
 
 // The schedule of a persistent launch, on the host (no device work; `cus` > 0: plan for that many compute units
@@ -799,6 +827,8 @@ int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, siz
   A.part = (float*)ws_tail; A.flags = (unsigned*)sync;
   A.err = (unsigned*)sync + (sync_bytes / sizeof(unsigned) - 1);
   A.snap = g3_snap;
+  A.xcd_contig = g3_xcd_contig;
+  A.rt = p.U / (unsigned)a.nkt;
   // (shares of >= one tile: boundaries are >= nkt apart and snapping only ever moves one ONTO a tile boundary, so a
   // tile has at most one interior cut; its second piece is its block's first work, published ~a tile before the
   // finisher reaches its own)

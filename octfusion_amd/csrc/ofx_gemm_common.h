@@ -79,7 +79,10 @@ static inline int ofx_launch_weight_scale(const float* W, int64_t sk, int64_t sn
   int64_t nb = (K * N + 256 * 16 - 1) / (256 * 16);
   nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
   weight_absmax_kernel<<<(unsigned)nb, 256, 0, st>>>(W, sk, sn, K, N, reinterpret_cast<unsigned*>(scale));
+  if (hipGetLastError() != hipSuccess) return OFX_ELAUNCH;
   weight_scale_finish_kernel<<<1, 1, 0, st>>>(fp16_operands, scale);
+  // (a failed scale launch would leave a garbage trailer that every later fp16x3 epilogue multiplies by: ADVICE r05)
+  if (hipGetLastError() != hipSuccess) return OFX_ELAUNCH;
   return OFX_OK;
 }
 

@@ -585,10 +585,13 @@ __device__ __forceinline__ float4 gn_store_planes(char* orow, int c, const float
   }
 }
 
-template <int MODE>
+// FIN: no mean / rstd arrays -- every block derives (mean, rstd) of the batch elements of its first and last row from the
+// fp64 sums into LDS (gn_apply_kernel's scheme: one launch less per norm), AFTER its rows have been requested.
+template <int MODE, bool FIN>
 __global__ void __launch_bounds__(256) gn_apply_oct_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int C,
                                                            const int32_t* __restrict__ bid,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const GnFin fin,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            int act, char* __restrict__ out, int64_t ldo,
                                                            int64_t aux_blocks, char* __restrict__ aux,
@@ -597,9 +600,9 @@ __global__ void __launch_bounds__(256) gn_apply_oct_kernel(const float* __restri
                                                            const int4* __restrict__ lhead,
                                                            const int32_t* __restrict__ lsrc, int64_t n_left,
                                                            int left_at_end) {
+  __shared__ float fin_ms[FIN ? 2 * 2 * 1024 : 1];       // [slot][mean | rstd][C]
   const int CT = C >> 2, RP = 256 / CT;
   const int cl = threadIdx.x % CT, rl = threadIdx.x / CT;
-  if (rl >= RP) return;                                   // (256 % (C / 4) != 0: the spare lanes have nothing to do; no barrier below)
   const int c = cl * 4;
   // leftover blocks: interleaved with the main blocks in dispatch order as in gn_apply_kernel (block i is the a-th
   // leftover block if the running share i * A / T steps at i), or all behind them (ofx_set_gn_left_place(1), A/B).
@@ -619,34 +622,96 @@ __global__ void __launch_bounds__(256) gn_apply_oct_kernel(const float* __restri
   }
   const int64_t aux_id = a_before, main_id = (int64_t)blockIdx.x - a_before;
   const int64_t o = main_id * RP + rl;
-  if (!is_aux && o >= n_oct) return;
+  // (256 % (C / 4) != 0 leaves spare lanes; they and the lanes past the last octet / leftover row only attend the barrier)
+  const bool active = rl < RP && (is_aux ? aux_id * RP + rl < n_left : o < n_oct);
 
   int p0 = 0, p1 = 0;
   float4 v[8];
-  int b[8];
-  if (!is_aux) {
-    // the octet's entry range first (its latency runs under the row loads, and the entries can then be requested
-    // before the rows are waited for), then the eight rows and their batch ids
+  int b0v = 0;
+  unsigned bdiff = 0;              // bit j: row j of the octet belongs to another batch element than row 0 (the leaf prefix)
+  if (!is_aux && active) {
+    // the octet's entry range and the eight batch ids first (their latency runs under the row loads; the ids collapse
+    // to one id + a mask -- siblings share a batch element -- before the rows land, which frees seven registers), then
+    // the eight rows
     p0 = oct_ptr[o];
     p1 = oct_ptr[o + 1];
     const int64_t r0 = 8 * o - shift;
+    int b[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       int64_t r = r0 + j;
       r = r < 0 ? 0 : (r < n ? r : n - 1);                // (rows outside [0, n) are loaded clamped and never stored)
       b[j] = bid[r];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int64_t r = r0 + j;
+      r = r < 0 ? 0 : (r < n ? r : n - 1);
       v[j] = *reinterpret_cast<const float4*>(x + r * ldx + c);
     }
+    b0v = b[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) bdiff |= (b[j] != b0v ? 1u : 0u) << j;
   }
+  int4 hd = make_int4(0, 0, 0, 0);
+  if (is_aux && active) hd = lhead[aux_id * RP + rl];
+  int fb0 = -1, fb1 = -1;
+  if (FIN) {
+    if (!is_aux) {
+      int64_t ra = 8 * (main_id * RP) - shift, rz = 8 * (main_id * RP + RP) - shift - 1;
+      ra = ra < 0 ? 0 : (ra < n ? ra : n - 1);
+      rz = rz < 0 ? 0 : (rz < n ? rz : n - 1);
+      fb0 = bid[ra];
+      fb1 = bid[rz];
+    } else {
+      const int64_t ia = aux_id * RP, iz = ia + RP - 1 < n_left ? ia + RP - 1 : n_left - 1;
+      fb0 = lhead[ia < n_left ? ia : n_left - 1].w;
+      fb1 = lhead[iz].w;
+    }
+    const int cpg = C / fin.G;
+    for (int t = threadIdx.x; t < 2 * fin.G; t += 256) {
+      const int slot = t / fin.G, g = t - slot * fin.G;
+      if (slot == 1 && fb1 == fb0) continue;
+      float mm, rr;
+      gn_group_stats(fin, slot ? fb1 : fb0, g, C, mm, rr);
+      for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) {
+        fin_ms[(slot * 2 + 0) * 1024 + cc] = mm;
+        fin_ms[(slot * 2 + 1) * 1024 + cc] = rr;
+      }
+    }
+    __syncthreads();
+  }
+  if (!active) return;
   const float4 ww = *reinterpret_cast<const float4*>(w + c);
   const float4 bb = *reinterpret_cast<const float4*>(bias + c);
   int cb = -1;
   float4 m = make_float4(0.f, 0.f, 0.f, 0.f), rs = m;
+  auto stats_of = [&](int bq) {
+    if (FIN) {
+      if (bq == fb0 || bq == fb1) {
+        const int slot = bq == fb0 ? 0 : 1;
+        m = *reinterpret_cast<const float4*>(fin_ms + (slot * 2 + 0) * 1024 + c);
+        rs = *reinterpret_cast<const float4*>(fin_ms + (slot * 2 + 1) * 1024 + c);
+      } else {                                            // (tiny graph levels: a third batch element inside one block)
+        // four consecutive channels lie in at most two groups (channels per group >= 2): first and last channel's
+        const int cpg = C / fin.G;
+        const int ga = c / cpg, gb = (c + 3) / cpg;
+        float ma, ra, mb2, rb2;
+        gn_group_stats(fin, bq, ga, C, ma, ra);
+        mb2 = ma; rb2 = ra;
+        if (gb != ga) gn_group_stats(fin, bq, gb, C, mb2, rb2);
+        m = make_float4(ma, (c + 1) / cpg == ga ? ma : mb2, (c + 2) / cpg == ga ? ma : mb2, mb2);
+        rs = make_float4(ra, (c + 1) / cpg == ga ? ra : rb2, (c + 2) / cpg == ga ? ra : rb2, rb2);
+      }
+    } else {
+      m = *reinterpret_cast<const float4*>(mean + (int64_t)bq * C + c);
+      rs = *reinterpret_cast<const float4*>(rstd + (int64_t)bq * C + c);
+    }
+  };
   auto norm = [&](int bq, const float4& q) {
     if (bq != cb) {
       cb = bq;
-      m = *reinterpret_cast<const float4*>(mean + (int64_t)bq * C + c);
-      rs = *reinterpret_cast<const float4*>(rstd + (int64_t)bq * C + c);
+      stats_of(bq);
     }
     return make_float4(ofx_apply_act((q.x - m.x) * rs.x * ww.x + bb.x, act),
                        ofx_apply_act((q.y - m.y) * rs.y * ww.y + bb.y, act),
@@ -658,14 +723,10 @@ __global__ void __launch_bounds__(256) gn_apply_oct_kernel(const float* __restri
     // flattened the chain plan -> multi_seg -> seg_ptr -> col into lhead[idx] = (aux row, first source slot, sources,
     // batch element) + lsrc[]: two dependent loads before the rows instead of four, and the statistics of the batch
     // element (every source of a segment lies in the batch element of its row) are requested together with the sources.
-    const int64_t idx = aux_id * RP + rl;
-    if (idx >= n_left) return;
-    const int4 hd = lhead[idx];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (hd.z > 0) {
-      m = *reinterpret_cast<const float4*>(mean + (int64_t)hd.w * C + c);
-      rs = *reinterpret_cast<const float4*>(rstd + (int64_t)hd.w * C + c);
       cb = hd.w;
+      stats_of(hd.w);
       const int32_t pa = hd.y, pe = hd.y + hd.z;
       for (int32_t q0 = pa; q0 < pe; q0 += 4) {
         int64_t sr[4];
@@ -688,7 +749,7 @@ __global__ void __launch_bounds__(256) gn_apply_oct_kernel(const float* __restri
     return;
   }
   // ---- main rows of the octet; the first entries are requested now (two dependent loads deep, both L2 hits)
-  constexpr int NPRE = 3;
+  constexpr int NPRE = 2;              // (three prefetched entries cost the FIN instantiation its fifth wave per SIMD: 98 VGPRs)
   int2 ent[NPRE];
 #pragma unroll
   for (int k = 0; k < NPRE; ++k) ent[k] = p0 + k < p1 ? oct_ent[p0 + k] : make_int2(0, 0);
@@ -696,7 +757,9 @@ __global__ void __launch_bounds__(256) gn_apply_oct_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int64_t r = r0 + j;
-    const float4 y = norm(b[j], v[j]);
+    int bq = b0v;
+    if ((bdiff >> j) & 1u) bq = bid[r < 0 ? 0 : (r < n ? r : n - 1)];
+    const float4 y = norm(bq, v[j]);
     if (r >= 0 && r < n) v[j] = gn_store_planes<MODE>(out + r * ldo, c, y);
   }
   auto entry = [&](const int2 en) {
@@ -721,16 +784,18 @@ static int g_gn_left_end = 0;              // A/B knob (ofx_set_gn_left_place): 
 extern "C" int ofx_set_gn_left_place(int at_end) { g_gn_left_end = at_end ? 1 : 0; return OFX_OK; }
 
 extern "C" int ofx_gn_apply_planes_oct(const float* x, int64_t ldx, int64_t n, int C, const int32_t* batch_id,
-                                       const float* mean, const float* rstd, const float* w, const float* bias, int act,
+                                       const float* mean, const float* rstd, const double* sums, const float* count,
+                                       int groups, float eps, float count_eps, const float* w, const float* bias, int act,
                                        int mode, void* out, int64_t ldo_bytes, int64_t n_multi, void* aux,
                                        const int32_t* oct_ptr, const int32_t* oct_ent, int64_t n_own, int shift,
                                        const int32_t* left_head, const int32_t* left_src, int64_t n_left,
                                        void* stream) {
   const int chunk = g2_pairs(mode) ? 32 : 64;
-  if (mode < 1 || mode > 3 || !x || !batch_id || !mean || !rstd || !w || !bias || !out || !aux || n < 0 || C < chunk ||
+  GnFin f = {nullptr, nullptr, 1, eps, count_eps};
+  if (mode < 1 || mode > 3 || !x || !batch_id || !w || !bias || !out || !aux || n < 0 || C < chunk ||
       (C % chunk) || C > 1024 || ldx < C || (ldx & 3) || ldo_bytes < (int64_t)C * (g2_pairs(mode) ? 4 : 2) ||
       (ldo_bytes & 15) || ((uintptr_t)x & 15) || ((uintptr_t)out & 127) || ((uintptr_t)aux & 127) ||
-      ((uintptr_t)w & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)mean & 15) || ((uintptr_t)rstd & 15) || act < 0 ||
+      ((uintptr_t)w & 15) || ((uintptr_t)bias & 15) || !gn_fin_args(mean, rstd, sums, count, C, groups, f) || act < 0 ||
       act > 2 || (const void*)out == (const void*)x || n_multi < 0 || !oct_ptr || n_own < 0 || n_own > n_multi || (n_own > 0 && (!oct_ent || ((uintptr_t)oct_ent & 7))) || shift < 0 ||
       shift > 7 || !left_head || ((uintptr_t)left_head & 15) || !left_src || n_left < 1 || n_left > n_multi + 1 ||
       n_own + n_left != n_multi + 1)
@@ -741,14 +806,15 @@ extern "C" int ofx_gn_apply_planes_oct(const float* x, int64_t ldx, int64_t n, i
     const int64_t mb = ofx_cdiv(n_oct, RP), ab = ofx_cdiv(n_left, RP);
     const int grid = (int)(mb + ab);
     hipStream_t st = ofx_stream(stream);
-#define GN_GO(M_)                                                                                                    \
-  gn_apply_oct_kernel<M_><<<grid, 256, 0, st>>>(x, ldx, n, C, batch_id, mean, rstd, w, bias, act, (char*)out, ldo_bytes, \
-                                                ab, (char*)aux, oct_ptr,                                              \
-                                                reinterpret_cast<const int2*>(oct_ent), n_oct, shift,                 \
-                                                reinterpret_cast<const int4*>(left_head), left_src, n_left, g_gn_left_end)
-    if (mode == 2) GN_GO(2);
-    else if (mode == 3) GN_GO(3);
-    else GN_GO(1);
+#define GN_GO(M_, F_)                                                                                                \
+  gn_apply_oct_kernel<M_, F_><<<grid, 256, 0, st>>>(x, ldx, n, C, batch_id, mean, rstd, f, w, bias, act, (char*)out,     \
+                                                    ldo_bytes, ab, (char*)aux, oct_ptr,                               \
+                                                    reinterpret_cast<const int2*>(oct_ent), n_oct, shift,             \
+                                                    reinterpret_cast<const int4*>(left_head), left_src, n_left,       \
+                                                    g_gn_left_end)
+    if (mode == 2) { if (mean) GN_GO(2, false); else GN_GO(2, true); }
+    else if (mode == 3) { if (mean) GN_GO(3, false); else GN_GO(3, true); }
+    else { if (mean) GN_GO(1, false); else GN_GO(1, true); }
 #undef GN_GO
   }
   OFX_LAUNCH_CHECK();

@@ -276,7 +276,10 @@ class Downsample(nn.Module):
     @torch.no_grad()
     def forward(self, x, out=None, out_rows=None, out_planes=0):
         C = self.channels
-        if x.stride(0) != C and x.stride(1) == 1 and C % 32 == 0 and x.shape[0] % 8 == 0 and x.shape[0] and ops.zero_row(x.device).numel() >= C:
+        # (ofx_gather_gemm_f32 wants a 16-B aligned base and a row pitch of whole float4s; any other slice takes the
+        # reshape below, which copies)
+        if (x.stride(0) != C and x.stride(1) == 1 and C % 32 == 0 and x.shape[0] % 8 == 0 and x.shape[0]
+                and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and ops.zero_row(x.device).numel() >= C):
             # x is a column slice of a wider buffer (the zero-copy skip concatenation): x.view(-1, 8 C) would copy it
             # (two strided ATen copies per hr step, 47 us, until round 5) -- gather the eight children instead
             n = x.shape[0] // 8

@@ -274,7 +274,7 @@ def side_stream(device):
     return s
 
 
-# OFX_FORK=1 (default): work that does not depend on the activation chain -- the embedding MLPs of both nets, the 1x1
+# OFX_FORK=1 (default 0: measured slower inside a replayed hipGraph): work that does not depend on the activation chain -- the embedding MLPs of both nets, the 1x1
 # residual convolutions of the dense net's ResnetBlocks -- is issued on a second stream and joined where its result
 # is consumed.  Inside a captured step these become parallel branches of the hipGraph: ~19 launches of 5-15 us leave
 # the step's critical path.  (The sparse net's 1x1 skip convolutions stay on the main stream: next to a persistent
@@ -286,7 +286,12 @@ _FORK = {}
 def fork_stream(device, level=1):
     """(main, fork) streams of `device` when forking is on (FORK >= level) and the tensor lives on a HIP device, else
     (None, None).  The fork stream is NOT sampler.sample_loop's warm-up / capture stream (side_stream): a fork happens
-    inside a step."""
+    inside a step.
+    Allocator invariant: tensors produced on the fork stream are consumed on `main` without
+    `record_stream`.  That is safe only because EVERY fork begins with `fork.wait_stream(main)` (below) and callers join
+    with `main.wait_stream(fork)` before the result is read: a block the caching allocator hands out again on the fork
+    stream cannot be written before main has passed the wait of the next fork, i.e. after main has finished reading the
+    previous result.  Do not allocate on the fork stream outside a fork_stream() ... join pair."""
     if FORK < level or device.type != 'cuda':
         return None, None
     s = _FORK.get(device.index)
@@ -944,6 +949,14 @@ GN_FINALIZE_LAUNCH = False
 # (round 4, same box, same run: lr stage 1.052 -> 1.015 ms per step, hr 8.80 -> 8.74 with 2048 = the 16^3 level)
 GN_ROWS_TWO_KERNELS = int(os.environ.get('OFX_GN_ROWS_TWO_KERNELS', '2048'))
 GN_FUSE_AUX_FINALIZE = os.environ.get('OFX_GN_FUSE_AUX_FINALIZE', '0') == '1'
+# sibling-octet launch (ofx_gn_apply_planes_oct): derive mean / rstd per block inside the launch (no ofx_gn_finalize launch)
+GN_OCT_FINALIZE = os.environ.get('OFX_GN_OCT_FINALIZE', '1') == '1'
+# ... for tensors up to this many elements.  Every block repeats the finalize (64 threads x 2 cpg fp64 loads + a barrier before
+# its first row can be used): measured against the 4.7 us ofx_gn_finalize launch it wins on small launches (depth 5, C = 128:
+# 21.0 vs 28.2 us; depth 4, C = 256: 18.6 vs 27.2 us eager) and loses on long or wide ones (depth 6, C = 384: 181 vs 159 us;
+# depth 5, C = 768: 114 vs 98 us -- 24 channels per group, 8-row blocks), tools/gn_probe_oct.py.  The one-shape step (B = 1)
+# is almost entirely below the bar.
+GN_OCT_FINALIZE_MAX_ELEMS = int(os.environ.get('OFX_GN_OCT_FINALIZE_MAX_ELEMS', str(9 << 20)))
 # who writes the aux rows of a GroupNorm launch: 'oct' (default, round 6) = the thread that holds the sibling octet of their
 # sources in registers (ofx_gn_apply_planes_oct); 'block' (round 4) = the 64-row block that holds their sources, from its own
 # output; '' / '0' = separate aux blocks (round 3).  A/B: OFX_AUX_PLAN=oct|block|0
@@ -993,7 +1006,9 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
     # gn_apply 1.15 -> 1.47 ms per hr step, against 0.115 ms for the 18 finalize launches it removes.  So that case keeps
     # the 4 us finalize launch.  GN_FINALIZE_LAUNCH = True forces it everywhere, GN_FUSE_AUX_FINALIZE = True removes it (A/B).
     mean = rstd = None
-    if GN_FINALIZE_LAUNCH or (planes and aux_graph is not None and not GN_FUSE_AUX_FINALIZE):
+    oct_fin = (GN_OCT_FINALIZE and planes and aux_graph is not None and AUX_PLAN == 'oct' and len(aux_graph) > 4
+               and aux_graph[4] is not None and len(aux_graph[4]) == 5 and n * C <= GN_OCT_FINALIZE_MAX_ELEMS)
+    if GN_FINALIZE_LAUNCH or (planes and aux_graph is not None and not GN_FUSE_AUX_FINALIZE and not oct_fin):
         mean = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
         rstd = torch.empty(batch_size * C, dtype=torch.float32, device=dev)
         _meta('gn_finalize', 0, 24.0 * batch_size * C, (batch_size, C))
@@ -1020,12 +1035,12 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
                     plan, n_left = aux_graph[4]      # (int32 plan, leftover count): dual_octree.DualOctree.aux_plan
             aux = torch.empty((n_multi + 1) * ldo, dtype=torch.uint8, device=dev)
         _meta('gn_apply', 0, 8.0 * n * C + (n_multi + 1) * float(ldo), (n, C, 'planes+aux' if aux is not None else 'planes'))
-        if aux is not None and oct_plan is not None and mean is not None:
+        if aux is not None and oct_plan is not None and (mean is not None or oct_fin):
             op, shift, n_own, n_left, (o_ptr, o_ent, o_head, o_src) = oct_plan
             base = op.data_ptr()
-            call('ofx_gn_apply_planes_oct', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(w), ptr(b), ACT[act],
-                 planes, ptr(out), ldo, n_multi, ptr(aux), base + 4 * o_ptr, base + 4 * o_ent, n_own, shift,
-                 base + 4 * o_head, base + 4 * o_src, n_left, stream())
+            call('ofx_gn_apply_planes_oct', ptr(x), ldx, n, C, ptr(batch_id), ptr(mean), ptr(rstd), ptr(sums), ptr(count),
+                 groups, eps, count_eps, ptr(w), ptr(b), ACT[act], planes, ptr(out), ldo, n_multi, ptr(aux), base + 4 * o_ptr,
+                 base + 4 * o_ent, n_own, shift, base + 4 * o_head, base + 4 * o_src, n_left, stream())
             setattr(out, PLANES_ATTR, planes)
             setattr(out, AUX_ATTR, aux)
             return out

@@ -68,17 +68,22 @@ def test_octet_launch_matches_the_older_launches_and_the_oracle(kind, d, Cc, mod
     plan = doc.oct_plan(d)
     assert plan[1] == (8 - doc._leaf_base[d] % 8) % 8
     xg = x.to(dev())
-    saved = ops.AUX_PLAN
+    saved = (ops.AUX_PLAN, ops.GN_OCT_FINALIZE_MAX_ELEMS)
+    ops.GN_OCT_FINALIZE_MAX_ELEMS = 1 << 40
     outs = {}
     try:
-        for how in ('oct', 'block', ''):
-            ops.AUX_PLAN = how
+        for how in ('oct', 'block', '', 'oct_sepfin'):
+            ops.AUX_PLAN = how.split('_')[0]
+            ops.GN_OCT_FINALIZE = how != 'oct_sepfin'           # statistics finalised inside the launch (default) / by ofx_gn_finalize
             y = gn(xg, doc, d, act='silu', planes=mode)
             assert ops.planes_of(y) == mode
             outs[how] = (ops.planes_merge(y, mode), _aux_values(y, V, Cc, mode))
     finally:
-        ops.AUX_PLAN = saved
+        ops.AUX_PLAN, ops.GN_OCT_FINALIZE_MAX_ELEMS = saved
+        ops.GN_OCT_FINALIZE = True
     main, aux = outs['oct']
+    # the in-launch finalize does gn_finalize_kernel's arithmetic: same bits
+    assert torch.equal(main, outs['oct_sepfin'][0]) and torch.equal(aux, outs['oct_sepfin'][1])
     tol = 2e-3 if mode == 1 else (1e-5 if mode == 2 else 2e-6)
     e = errors(main, ref)
     assert e['rel_to_max'] < tol, e

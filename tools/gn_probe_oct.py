@@ -8,6 +8,7 @@ from octfusion_amd import _lib, ops, synthetic, modules as M
 from octfusion_amd.dual_octree import DualOctree
 from octfusion_amd.octree import split2octree_small, split2octree_large
 dev = torch.device('cuda:0'); torch.set_grad_enabled(False)
+ops.GN_OCT_FINALIZE_MAX_ELEMS = 1 << 40       # (the A/B below decides per shape)
 which = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith('-') else 'both'
 out = sys.argv[sys.argv.index('--out') + 1] if '--out' in sys.argv else None
 def timeit(fn, n=20):
@@ -34,12 +35,15 @@ def run(doc, shapes, tag):
         t_blk = timeit(lambda: f(planes=3, aux_graph=(seg_ptr, col, multi_seg, V, bp)))
         t_sep = timeit(lambda: f(planes=3, aux_graph=(seg_ptr, col, multi_seg, V)))
         t_oct2 = timeit(lambda: f(planes=3, aux_graph=(seg_ptr, col, multi_seg, V, op)))
+        ops.GN_OCT_FINALIZE = False
+        t_oct_sep = timeit(lambda: f(planes=3, aux_graph=(seg_ptr, col, multi_seg, V, op)))
+        ops.GN_OCT_FINALIZE = True
         r = dict(tree=tag, depth=d, C=C, N=N, V=V, oct_owned=op[2], oct_left=op[3], block_left=bp[1], us_no_aux=t_plain,
-                 us_oct=min(t_oct, t_oct2), us_block=t_blk, us_sep=t_sep,
+                 us_oct=min(t_oct, t_oct2), us_oct_separate_finalize=t_oct_sep, us_block=t_blk, us_sep=t_sep,
                  TBps_oct=(8e-6 * N * C + 4e-6 * (V + 1) * C) / min(t_oct, t_oct2))
         rows.append(r)
-        print('%s d%d C=%d N=%d V=%d (oct-owned %d, left %d | block left %d): no aux %.1f us | oct %.1f | block %.1f | sep %.1f  -> %.2f TB/s' % (
-            tag, d, C, N, V, op[2], op[3], bp[1], t_plain, r['us_oct'], t_blk, t_sep, r['TBps_oct']), flush=True)
+        print('%s d%d C=%d N=%d V=%d (oct-owned %d, left %d | block left %d): no aux %.1f us | oct %.1f (with the finalize launch %.1f) | block %.1f | sep %.1f  -> %.2f TB/s' % (
+            tag, d, C, N, V, op[2], op[3], bp[1], t_plain, r['us_oct'], t_oct_sep, t_blk, t_sep, r['TBps_oct']), flush=True)
 oc = split2octree_small(synthetic.shell6_split(8).to(dev), 6, 4)
 if which in ('hr', 'both'):
     run(DualOctree(oc), [(6, 128), (6, 256), (6, 384), (5, 128), (5, 256), (5, 384), (5, 768), (4, 256), (4, 512), (4, 64)], 'shell6x8')

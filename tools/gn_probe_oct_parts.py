@@ -31,7 +31,7 @@ def run(doc, shapes, tag):
         zptr = torch.zeros(n_oct + 1, dtype=torch.int32, device=dev)
         zero_left = torch.zeros(8, dtype=torch.int32, device=dev)
         def go(optr, nown, left, nleft):
-            call('ofx_gn_apply_planes_oct', ptr(x), C, N, C, ptr(bid), ptr(mean), ptr(rstd), ptr(w), ptr(b), 1, 3, ptr(out), C * 4,
+            call('ofx_gn_apply_planes_oct', ptr(x), C, N, C, ptr(bid), ptr(mean), ptr(rstd), None, None, 32, 1e-5, 1e-5, ptr(w), ptr(b), 1, 3, ptr(out), C * 4,
                  nown + nleft - 1, ptr(aux), optr, base + 4 * o_ent, nown, shift, left, base + 4 * o_src, nleft, stream())
         t_main = timeit(lambda: go(ptr(zptr), 0, ptr(zero_left), 1))
         t_own = timeit(lambda: go(base + 4 * o_ptr, n_own, ptr(zero_left), 1)) if n_own else float('nan')
@@ -42,7 +42,7 @@ def run(doc, shapes, tag):
         seq[o_ent:o_ent + 2 * n_own:2] = torch.arange(1, n_own + 1, dtype=torch.int32, device=dev)
         sbase = seq.data_ptr()
         def go2():
-            call('ofx_gn_apply_planes_oct', ptr(x), C, N, C, ptr(bid), ptr(mean), ptr(rstd), ptr(w), ptr(b), 1, 3, ptr(out), C * 4,
+            call('ofx_gn_apply_planes_oct', ptr(x), C, N, C, ptr(bid), ptr(mean), ptr(rstd), None, None, 32, 1e-5, 1e-5, ptr(w), ptr(b), 1, 3, ptr(out), C * 4,
                  n_own, ptr(aux), sbase + 4 * o_ptr, sbase + 4 * o_ent, n_own, shift, ptr(zero_left), sbase + 4 * o_src, 1, stream())
         t_seq = timeit(go2) if n_own else float('nan')
         print('   owned rows with sequential ids: %.1f us' % t_seq)

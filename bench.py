@@ -411,7 +411,7 @@ def gather_microbench(doc, dev, C=128, iters=20):
 
 
 KERNEL_SOURCES = ('ofx_gemm3.hip', 'ofx_planes.h', 'ofx_gemm2.hip', 'ofx_gemm.hip', 'ofx_gemm_common.h')
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r05', 'pmc_traffic.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r06', 'pmc_traffic.json')
 
 
 def kernel_source_hash():
@@ -455,20 +455,24 @@ def tail_summary(tail, steps, peak_tf, step_ms, eager_ms):
             conv_ms += ms
             continue
         kind, fl, nb, tag = meta if meta is not None else (name.replace('ofx_', ''), 0.0, 0.0, None)
-        c = cls.setdefault(kind, [0, 0.0, 0.0, 0.0])
+        c = cls.setdefault(kind, [0, 0.0, 0.0, 0.0, 0.0])
         c[0] += 1; c[1] += ms; c[2] += fl; c[3] += nb
+        c[4] += 1e3 * max(nb / (HBM_PEAK_GBS * 1e9), fl / (peak_tf * 1e12))       # the launch's own ideal time
         if tag is not None:
             sh = shapes.setdefault((kind,) + tuple(tag), [0, 0.0, fl, nb])
             sh[0] += 1; sh[1] += ms
     rows = {}
     tot_ms = tot_n = 0.0
-    for kind, (n, ms, fl, nb) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
+    for kind, (n, ms, fl, nb, ideal_ms) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
         bound = TAIL_BOUND.get(kind, 'hbm')
         t_s = ms * 1e-3
         r = {'launches_per_step': n / steps, 'ms_per_step': ms / steps, 'bound': bound,
              'algorithmic_GFLOP_per_step': fl / steps / 1e9, 'algorithmic_MB_per_step': nb / steps / 1e6,
              'TFLOPs': fl / t_s / 1e12 if t_s else None, 'GBps': nb / t_s / 1e9 if t_s else None}
         r['frac'] = (r['TFLOPs'] / peak_tf if bound == 'mfma' else r['GBps'] / HBM_PEAK_GBS) if t_s else None
+        # the class against max(bytes / HBM peak, flops / matrix peak) taken PER LAUNCH: a class like dense_gemm mixes
+        # matrix-bound members (unpool, qkv) with HBM-bound ones (the 1x1 skip convolutions read x once: 3-4 flops per byte)
+        r['frac_max_rule'] = ideal_ms / ms if ms else None
         rows[kind] = r
         tot_ms += ms; tot_n += n
     top = sorted(shapes.items(), key=lambda kv: -kv[1][1])[:16]
@@ -485,7 +489,7 @@ def tail_summary(tail, steps, peak_tf, step_ms, eager_ms):
                             'GBps': v[3] * v[0] / (v[1] * 1e-3) / 1e9 if v[1] else None} for k, v in top],
             'note': 'HIP events around every libofx entry-point call of the eager re-run (events between calls add '
                     'host gaps: "unattributed" = eager step time minus the brackets = torch-native copies / fills + '
-                    'gaps); kernel-symbol view: profiles/r05/bench_r05_<workload>_kernel_stats.csv'}
+                    'gaps); kernel-symbol view: profiles/r06/bench_r06_<workload>_kernel_stats.csv'}
 
 
 def per_layer(prof):
@@ -720,7 +724,8 @@ def main():
                          'frac': dom['hbm_frac'] if bound == 'hbm' else dom['mfma_frac'],
                          'traffic': None})
             roof.update(dom)
-            tpath = PMC_FILE.replace('.json', '_feature.json') if args.workload == 'feature' else PMC_FILE
+            # counters of the workload's OWN shapes (hr: shell-6 x 8, hr_cond: shell-6 x 4, feature: shell-8 x 8)
+            tpath = PMC_FILE.replace('.json', '_%s.json' % args.workload) if args.workload in ('feature', 'hr_cond') else PMC_FILE
             if dom_is_planes and os.path.exists(tpath):       # (the counters are the planes GraphConv's: nothing to say about the dense lr stage)
                 try:
                     pj = json.load(open(tpath))
@@ -728,7 +733,7 @@ def main():
                     kernels = [L_.get('kernel', '') for L_ in pj.get('layers', [])]
                     if not kernels or not all(want_k and want_k in k_ for k_ in kernels):
                         # counters taken on another instantiation than the one this run timed say nothing about it
-                        roof['traffic_note'] = ('profiles/r05/pmc_traffic.json holds counters of %s, this run timed %s...>: '
+                        roof['traffic_note'] = ('profiles/r06/pmc_traffic*.json holds counters of %s, this run timed %s...>: '
                                                 'not reported' % (sorted(set(kernels)), want_k))
                     elif pj.get('kernel_source_sha16') == kernel_source_hash():
                         # counters exist for four probe layers (tools/pmc_probe2.py); `traffic` is the HBM byte count
@@ -739,15 +744,16 @@ def main():
                         if args.workload == 'feature':       # depth-8 64 -> 64 layer of the shell-8 x 8 tree
                             n8, e8 = wl.doc.csr(8)[2], wl.doc.csr(8)[3]
                             roof['traffic_layer_algorithmic_bytes'] = 4.0 * (e8 * 64 + n8 * 64 + 7 * 71 * 64) + 8.0 * e8
-                        else:                                # depth-6 128 -> 128 layer of the shell-6 x 8 tree
-                            roof['traffic_layer_algorithmic_bytes'] = 4.0 * (1629600 * 128 + 217008 * 128 + 931 * 128) + 8.0 * 1629600
+                        else:                                # depth-6 128 -> 128 layer of this workload's shell-6 batch
+                            n6, e6 = wl.doc.csr(6)[2], wl.doc.csr(6)[3]
+                            roof['traffic_layer_algorithmic_bytes'] = 4.0 * (e6 * 128 + n6 * 128 + 931 * 128) + 8.0 * e6
                         roof['traffic_per_layer'] = [{'layer': L_['layer'], 'kernel': L_['kernel'], 'hbm_bytes': L_['hbm_bytes_per_launch'],
                                                       'mfma_busy_of_clocked_cycles': L_['mfma_busy_frac_of_clocked_simd_cycles'],
                                                       'clock_ghz': L_['gpu_clock_ghz_under_kernel']} for L_ in pj['layers']]
                         roof['traffic_source'] = pj.get('source')
                         roof['mfma_pmc'] = pj.get('mfma')
                     else:
-                        roof['traffic_note'] = ('profiles/r05/pmc_traffic.json was measured on kernel sources %s, this '
+                        roof['traffic_note'] = ('profiles/r06/pmc_traffic*.json was measured on kernel sources %s, this '
                                                 'build is %s: not reported' % (pj.get('kernel_source_sha16'), kernel_source_hash()))
                 except Exception as e:      # noqa: BLE001
                     roof['traffic_note'] = 'pmc_traffic.json unreadable: %s' % e
@@ -853,6 +859,15 @@ def main():
             ops.USE_PLANES = True
             _lib.call('ofx_set_gconv_persistent', 1)
         res['side_runs'] = extras
+        if 'fp16_single_pass' in extras:
+            # BASELINE configs[4] names "fp16 MFMA": the single-pass fp16 contraction as a peer of `value` (eager launches).
+            # It is NOT the shipped default: element-wise p99.9 2e-2 against the fp64 oracle (whole-step rel-to-max 4.5e-4,
+            # inside north_star's 1e-3) -- DESIGN section 2, tests/test_gpu_cascade.py::test_cascade_in_fp16_single_pass
+            fx = extras['fp16_single_pass']
+            res['value_fp16_single_pass'] = world * 1e3 / fx['ms_per_step']
+            res['roofline_fp16_single_pass'] = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'achieved': fx['graphconv_GBps'],
+                                                'frac': fx['graphconv_hbm_frac'], 'mfma_frac_of_2500': fx['graphconv_mfma_frac'],
+                                                'kernel': 'gconv3_kernel<1, *, *> (one v_mfma_f32_32x32x16_f16 per product)'}
         try:
             sus = mfma_sustained_probe(dev)
             roof = res['roofline']

@@ -396,6 +396,18 @@ int ofx_graphconv_narrow_in(const float* x, int64_t ldx, int cin, int64_t n_node
                             const int32_t* col, const uint8_t* node_type, int nt, const float* W, int cout,
                             const float* bias, const int32_t* batch_id, float* out, int64_t ldc,
                             double* stats /* optional */, int64_t stats_ld, void* ws, size_t ws_bytes, void* stream);
+/* ofx_graphconv_narrow_in_tab (round 6): ofx_graphconv_narrow_in through the branch-free gather table -- nbr_ext [n, 7]
+ * / multi_seg [n_multi] of ofx_graph_primary_ext; `aux` = scratch of (n_nodes + n_multi + 1) * (cin <= 4 ? 32 : 64) bytes
+ * (16-B aligned) that a pre-pass fills with one record per gatherable id (x + node type of a row; x mean + node-type
+ * counts of a multi-neighbour segment): a segment then costs one table entry + one aligned record.  One persistent launch of two
+ * 512-thread blocks per CU; a block walks row groups with the next group's gathers in flight under the current
+ * group's MFMAs and stores.  Same results as ofx_graphconv_narrow_in to fp32 rounding (the segment means of
+ * multi-neighbour segments are taken before, not after, the weight product's inputs are staged: same arithmetic). */
+int ofx_graphconv_narrow_in_tab(const float* x, int64_t ldx, int cin, int64_t n_nodes, const int32_t* seg_ptr,
+                                const int32_t* col, const int32_t* nbr_ext, const int32_t* multi_seg, int64_t n_multi,
+                                void* aux, const uint8_t* node_type, int nt, const float* W, int cout, const float* bias,
+                                const int32_t* batch_id, float* out, int64_t ldc, double* stats /* optional */,
+                                int64_t stats_ld, void* ws, size_t ws_bytes, void* stream);
 int ofx_narrow_out_pack(const float* W, int C, int nt, int cout, int pw, float* Wd, void* stream);
 int ofx_narrow_out_type_term(const float* type_frac, int64_t ldt, int nt, int64_t n_nodes, const float* W, int C,
                              int cout, const float* bias, float* type_term, void* stream);
@@ -490,6 +502,24 @@ int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int cin, int64_t
  * per block; 2: persistent with pure stream-K (no whole-tile rounds); 3: as 1 with share boundaries snapped towards the
  * tile boundary instead of to the nearest legal cut -- A/B knobs, same values */
 int ofx_set_gconv_persistent(int on);
+/* ofx_gemm_planes (round 6): out[m, :] = A[row_tab[m, 0], :] @ W (+ bias) on the data path of the planes GraphConv
+ * (persistent stream-K blocks, LDS-DMA staging, fp16x3 / bf16x3 MFMA; csrc/ofx_gemm3.hip with one "direction") -- the
+ * reference's Upsample GEMM x[n, C] @ W.flatten(1) -> [n, 8 C] (modules.py:430-446, call site :458-467) for the
+ * non-leaf rows of a graph depth.  ap: pair planes of A (mode 2 / 3; 128-B aligned rows); row_tab: int32 [M, 7], 16-B
+ * aligned, + 16 B of readable slack: column 0 = the source row in [0, n_a) of output row m (the other six columns are
+ * converted but never dereferenced: any row in [0, n_a)); W2 from ofx_pack_gemm_planes ((K / 32) * N * 128 + 128 bytes,
+ * ofx_gemm_planes_packed_bytes); out fp32 rows, or with out_mode 2 / 3 pair planes (what the next GraphConv gathers).
+ * ws / sync: the workspace and flag words of ofx_graphconv_fwd_planes (same protocol, same sticky error word).
+ * Returns OFX_OK, a negative status, or 1 when the shape does not qualify (fewer than 8 k-steps of 32 channels, N < 128,
+ * too few tiles, workspace too small): nothing was launched and the caller uses ofx_gemm_f32 / ofx_gemm_f32_planes. */
+int64_t ofx_gemm_planes_packed_bytes(int K, int N, int mode);
+int ofx_pack_gemm_planes(const float* W, int64_t sk, int64_t sn, int K, int N, int mode, void* out, void* stream);
+int ofx_gemm_planes(const void* ap, int64_t lda_bytes, int64_t n_a, int64_t M, int K, const int32_t* row_tab,
+                    const void* W2, int N, const float* bias, float* out, int64_t ldc, int out_mode, void* ws,
+                    size_t ws_bytes, void* sync, size_t sync_bytes, int mode, void* stream);
+/* A/B knob of the dense GEMM (csrc/ofx_gemm.hip): max_n > 0 -> GEMMs with N <= max_n and M >= 65 536 rows use 64-column
+ * tiles (three blocks per CU instead of two); 0 = off. */
+int ofx_set_gemm_bn64(int max_n);
 /* A/B knob of the persistent launch's tile order: 1 = every XCD walks one contiguous range of tiles over the whole
  * launch (csrc/ofx_gemm3.hip, Gemm3Args::xcd_contig), 0 = the XCDs interleave inside every whole-tile round. */
 int ofx_set_gconv_xcd_contig(int on);

@@ -95,6 +95,8 @@ _SIGS = {
     'ofx_gn_apply_rows': (c_i, [], False),
     'ofx_set_attention_split': (c_i, [c_i], True),
     'ofx_gather_gemm_f32': (c_i, [c_p, c_l, c_i, c_i, c_l, c_l, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_sz, c_i, c_p], True),
+    'ofx_graphconv_narrow_in_tab': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_l,
+                                          c_p, c_sz, c_p], True),
     'ofx_graphconv_narrow_in': (c_i, [c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_sz, c_p], True),
     'ofx_narrow_out_pack': (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p], True),
     'ofx_narrow_out_type_term': (c_i, [c_p, c_l, c_i, c_l, c_p, c_i, c_i, c_p, c_p, c_p], True),
@@ -122,6 +124,10 @@ _SIGS = {
                                        c_p], True),
     'ofx_set_gconv_persistent': (c_i, [c_i], True),
     'ofx_set_gconv_xcd_contig': (c_i, [c_i], True),
+    'ofx_set_gemm_bn64': (c_i, [c_i], True),
+    'ofx_gemm_planes_packed_bytes': (c_l, [c_i, c_i, c_i], False),
+    'ofx_pack_gemm_planes': (c_i, [c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_p], True),
+    'ofx_gemm_planes': (c_i, [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_p, c_sz, c_p, c_sz, c_i, c_p], False),
     'ofx_gconv3_plan': (c_i, [c_l, c_i, c_i, c_i, c_i, c_i, c_p, c_l], False),
     'ofx_set_gconv2_variant': (c_i, [c_i], True),
     'ofx_set_gconv2_debug': (c_i, [c_p], True),

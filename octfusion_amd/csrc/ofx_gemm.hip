@@ -899,6 +899,8 @@ __global__ void pack_bf16x3_kernel(const float* __restrict__ Wp, int64_t Kp, int
   }
 }
 static int g_precision = 3;
+static int g_gemm_bn64 = 0;                 // 0: off; n: dense GEMMs with N <= n and M >= 64 k rows use 64-column tiles
+extern "C" int ofx_set_gemm_bn64(int max_n) { g_gemm_bn64 = max_n < 0 ? 0 : max_n; return OFX_OK; }
 // the 16-bit planes behind the fp32 pack follow the precision that is set WHEN THE WEIGHTS ARE PACKED (bf16 pairs for
 // precisions 0 / 2, fp16 pairs for 3; unused by 1): the Python cache keys its packs on the precision, C callers re-pack
 // after ofx_set_precision
@@ -1124,7 +1126,11 @@ static int launch_gemm(GemmArgs& g, float* ws, size_t ws_bytes, hipStream_t st) 
     g.vec4 = g.N % 4 == 0 && al16(g.out) && g.ldc % 4 == 0 && (!g.res || (al16(g.res) && g.ldr % 4 == 0)) &&
              (!g.emb || (al16(g.emb) && g.lde % 4 == 0)) && (!g.bias || al16(g.bias));
   }
-  const int bn = g.N <= 32 ? 32 : (g.N <= 64 ? 64 : 128);
+  int bn = g.N <= 32 ? 32 : (g.N <= 64 ? 64 : 128);
+  // A/B knob (ofx_set_gemm_bn64): 64-column tiles for the long, narrow, HBM-bound GEMMs (the 1x1 skip convolutions:
+  // N = 128, M >= 64 k rows) -- 138 instead of 202 VGPRs, three blocks per CU instead of two, i.e. half as many more
+  // row loads in flight, at the price of reading every A tile twice (the second time from L2)
+  if (g_gemm_bn64 && MODE == MODE_DENSE && bn == 128 && g.N <= g_gemm_bn64 && g.M >= 65536) bn = 64;
   g.ntm = (int)ofx_cdiv(g.M, BM);
   g.ntn = (int)ofx_cdiv(g.N, bn);
   const int nkt = (int)(g.Kp / BK);

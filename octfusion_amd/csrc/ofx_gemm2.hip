@@ -695,12 +695,12 @@ extern "C" int64_t ofx_planes_packed_bytes(int cin, int nt, int cout, int mode) 
 
 __global__ void __launch_bounds__(256) planes_pack_kernel(const float* __restrict__ W, int64_t sk, int64_t sn, int cin,
                                                           int ntc, int64_t N, int64_t nkt, int mode,
-                                                          char* __restrict__ out) {
+                                                          char* __restrict__ out, int ndir = 7) {
   // one thread per 16-B piece: (k tile, column, piece)
   const int64_t total = nkt * N * 8;
   const float wscale = reinterpret_cast<const float*>(out + nkt * N * G2_LINE)[1];     // written by ofx_launch_weight_scale
   const int ch = g2_pairs(mode) ? 32 : 64;
-  const int64_t Kf = 7 * (int64_t)cin;
+  const int64_t Kf = ndir * (int64_t)cin;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int p = (int)(t & 7);
     const int64_t n = (t >> 3) % N, kt = (t >> 3) / N;
@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(256) planes_pack_kernel(const float* __restric
       if (k < Kf) {
         const int64_t dir = k / cin, c = k - dir * cin;
         src = dir * (cin + ntc) + c;
-      } else if (ntc > 0 && k - Kf < 7 * (int64_t)ntc) {
+      } else if (ntc > 0 && k - Kf < ndir * (int64_t)ntc) {
         const int64_t kk = k - Kf, dir = kk / ntc, ty = kk - dir * ntc;
         src = dir * (cin + ntc) + cin + ty;
       }
@@ -747,6 +747,24 @@ extern "C" int ofx_pack_weights_planes(const float* W, int64_t sk, int64_t sn, i
     return OFX_ELAUNCH;
   planes_pack_kernel<<<ofx_grid(nkt * cout * 8, 256), 256, 0, ofx_stream(stream)>>>(W, sk, sn, cin, ntc,
                                                                                     cout, nkt, mode, (char*)out);
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+// Dense weights [K, N] (element (k, n) at W[k * sk + n * sn]) as [k tile][N][128-B line] for ofx_gemm_planes: the
+// GraphConv pack with ONE direction and no node-type rows; (K / 32) * N * 128 + 128 bytes.
+extern "C" int64_t ofx_gemm_planes_packed_bytes(int K, int N, int mode) {
+  if (!g2_pairs(mode) || K < 32 || (K % 32) || N < 1) return 0;
+  return (int64_t)(K / 32) * N * G2_LINE + G2_TRAILER;
+}
+extern "C" int ofx_pack_gemm_planes(const float* W, int64_t sk, int64_t sn, int K, int N, int mode, void* out,
+                                    void* stream) {
+  if (!W || !out || !g2_pairs(mode) || K < 32 || (K % 32) || N < 1 || ((uintptr_t)out & 15)) return OFX_EINVAL;
+  const int64_t nkt = K / 32;
+  if (ofx_launch_weight_scale(W, sk, sn, K, N, mode != 2 ? 1 : 0, reinterpret_cast<float*>((char*)out + nkt * N * G2_LINE),
+                              ofx_stream(stream)))
+    return OFX_ELAUNCH;
+  planes_pack_kernel<<<ofx_grid(nkt * N * 8, 256), 256, 0, ofx_stream(stream)>>>(W, sk, sn, K, 0, N, nkt, mode, (char*)out, 1);
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }
@@ -821,7 +839,7 @@ static int g3_auto_wm(int64_t M, int cout, int nkt, int ni) {
 }
 // persistent stream-K kernel (ofx_gemm3.hip); returns 1 when the shape / workspace does not qualify
 int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, size_t ws_tail_bytes, void* sync,
-                      size_t sync_bytes, hipStream_t st);
+                      size_t sync_bytes, hipStream_t st, int nd = 7);
 static int g2_persistent = 1;               // 1 (default): persistent stream-K blocks where the shape qualifies
 void ofx_gconv3_set_hybrid(int on);          // ofx_gemm3.hip
 void ofx_gconv3_set_snap(int near);          // ofx_gemm3.hip
@@ -944,6 +962,41 @@ extern "C" int ofx_graphconv_fwd_planes(const void* xp, int64_t ldx_bytes, int c
     rc = ofx_launch_stats_reduce(g, 64, st);
     if (rc) return rc;
   }
+  OFX_LAUNCH_CHECK();
+  return OFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[m, :] = A[row_tab[m, 0], :] @ W (+ bias) on the planes data path (persistent stream-K blocks, csrc/ofx_gemm3.hip
+// with ND = 1): the reference's Upsample GEMM (modules.py:430-446, x[n, C] @ W.flatten(1) -> [n, 8 C]) for the non-leaf
+// rows of a graph depth.  ap: operand planes of A (pair modes 2 / 3), row_tab: int32 [M, 7] whose FIRST column is the
+// source row of output row m in [0, n_a) (the other six are ignored by the kernel but must be readable: pass any valid
+// row; + 16 B of slack behind the table, 16-B aligned), W2 from ofx_pack_gemm_planes, out fp32 or -- out_mode 2 / 3 --
+// pair planes.  Returns OFX_OK, a failure status, or 1 when the shape does not qualify (K / 32 < 8 k-steps, too few
+// tiles, workspace too small): the caller then uses ofx_gemm_f32(_planes).
+extern "C" int ofx_gemm_planes(const void* ap, int64_t lda_bytes, int64_t n_a, int64_t M, int K, const int32_t* row_tab,
+                               const void* W2, int N, const float* bias, float* out, int64_t ldc, int out_mode, void* ws,
+                               size_t ws_bytes, void* sync, size_t sync_bytes, int mode, void* stream) {
+  if (!g2_pairs(mode) || !ap || !row_tab || !W2 || !out || M < 0 || n_a < 1 || K < 32 || (K % 32) || N < 4 || (N & 3) ||
+      lda_bytes < (int64_t)K * 4 || (lda_bytes & 127) || ((uintptr_t)ap & 127) || ((uintptr_t)W2 & 127) || ldc < N ||
+      (ldc & 3) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15)) ||
+      (out_mode && (!g2_pairs(out_mode) || (ldc & 31) || (N & 31) || ((uintptr_t)out & 127))))
+    return OFX_EINVAL;
+  if (M == 0) return OFX_OK;
+  if (!sync || !ws || N < 128) return 1;
+  Gemm2Args a = {};
+  a.xp = (const char*)ap; a.ldx = lda_bytes; a.aux = (const char*)ap; a.n_src = n_a; a.nbr_ext = row_tab;
+  a.tfp = (const char*)ap; a.ldt = lda_bytes;
+  a.W2 = (const char*)W2;
+  a.tpd = K / 32; a.nkt_g = a.tpd; a.nkt = a.tpd;
+  GemmArgs& g = a.e;
+  g.M = M; g.N = N; g.K = g.Kp = K; g.bias = bias; g.out = out; g.ldc = ldc; g.nsplit = 1; g.out_planes = out_mode;
+  g.oscale_p = reinterpret_cast<const float*>((const char*)W2 + (int64_t)a.nkt * N * G2_LINE);
+  g.vec4 = 1;
+  g.ntn = (int)ofx_cdiv(g.N, 128);
+  const int wm = g3_auto_wm(M, N, a.nkt, 2);
+  const int rc = ofx_launch_gconv3(a, mode, wm, 2, ws, ws_bytes, sync, sync_bytes, ofx_stream(stream), 1);
+  if (rc) return rc;
   OFX_LAUNCH_CHECK();
   return OFX_OK;
 }

@@ -97,7 +97,11 @@ __device__ __forceinline__ void g3_wait_lgkm0(G3Raw& R) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.v[0]), "+v"(R.v[1]), "+v"(R.v[2]), "+v"(R.v[3])::"memory");
 }
 
-template <int PREC, int WM, int NI>
+// ND: gathered "directions" per channel chunk.  7 = the dual-octree GraphConv; 1 = a plain GEMM out = A[row map] @ W on
+// the same data path (round 6: GraphUpsample's [n, C] x [C, 8 C] unpool -- the register-staged dense kernel needs 62 B/clk
+// of operands from L2 against the 35 B/clk the path delivers, this one shares the weight tile through LDS): the table
+// has one live column (the source row of output row m), no node-type tiles, everything else is the same loop.
+template <int PREC, int WM, int NI, int ND = 7>
 __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
   typedef G2Half<PREC, NI> Half;
   typedef G3Cfg<WM, NI> CF;
@@ -208,7 +212,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
   auto tile_of = [&](int it) {
     Tile T;
     if (it < nkt_g) {
-      const int chunk = it / 7, dir = it - chunk * 7;
+      const int chunk = it / ND, dir = it - chunk * ND;
       T.tcol = dir; T.ktw = dir * tpd + chunk; T.base = xp_s + (int64_t)chunk * G2_LINE;
     } else {
       T.tcol = 7; T.ktw = it; T.base = tfp_s + (int64_t)(it - nkt_g) * G2_LINE;
@@ -479,7 +483,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
     // batch element of this wave's first output row, for the time-embedding line of the epilogue requests (asked for
     // here so that its latency is this wait's, not the last k-steps')
     int b0v = 0;
-    const bool emb_line = g.emb && !g.bias;
+    const bool emb_line = ND != 1 && g.emb && !g.bias;
     if (emb_line) {
       const int64_t mw = m0 + (wid >> 1) * (G2_MI * 32);
       g2_req32(b0v, g.bid + (mw < Mrows - 1 ? mw : Mrows - 1));
@@ -519,7 +523,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
     int gd, gc;
     {
       const int ti = k0 + 2;
-      gc = ti / 7; gd = ti - gc * 7;                                     // (only meaningful while ti < nkt_g)
+      gc = ti / ND; gd = ti - gc * ND;                                   // (only meaningful while ti < nkt_g)
     }
     auto next_tile = [&]() {
       const int ti = it + 2;
@@ -528,7 +532,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
       T.tcol = gat ? gd : 7;
       T.ktw = gat ? gd * tpd + gc : ti;
       T.base = (gat ? xp_s : tfp_s) + (int64_t)(gat ? gc : ti - nkt_g) * G2_LINE;
-      const int wrap = gd == 6;
+      const int wrap = gd == ND - 1;
       gd = wrap ? 0 : gd + 1;
       gc += wrap;
       return T;
@@ -548,13 +552,14 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
     auto step = [&](const Tile& T, auto lo_tag, auto hi_tag) {
       constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;
       constexpr bool LAST = HI > LO;
-      constexpr int NEPI = (LO < 1 && HI > 0 ? g2_epi_slice_loads<G2_NI>(0) : 0) + 4 * ((HI > 1 ? HI : 1) - (LO > 1 ? LO : 1));
+      // (ND = 1, the dense GEMM: no residual / embedding / statistics operands -> nothing is requested)
+      constexpr int NEPI = ND == 1 ? 0 : (LO < 1 && HI > 0 ? g2_epi_slice_loads<G2_NI>(0) : 0) + 4 * ((HI > 1 ? HI : 1) - (LO > 1 ? LO : 1));
       if constexpr (CF::NBUF == 3) {
         // table reads | wait F0 (4 younger) | {MFMA F0, read F1, request k tile it+2} | barrier | {MFMA F1, read F0'}
         load_idx(T, I);
         g2_wait_lgkm<4, PREC>(F0);
         G3_FENCE();
-        if constexpr (LAST) {
+        if constexpr (LAST && ND != 1) {
           epi_request(lo_tag, hi_tag);
           G3_FENCE();
         }
@@ -568,7 +573,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
         // buffer k tile `it` just left}
         g2_wait_lgkm<0, PREC>(F0);
         G3_FENCE();
-        if constexpr (LAST) {
+        if constexpr (LAST && ND != 1) {
           epi_request(lo_tag, hi_tag);
           G3_FENCE();
         }
@@ -638,7 +643,7 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
       drain(Tn, false, std::integral_constant<int, GLDS>());
       ++it;
     }
-    g2_epilogue_landed(P);
+    if constexpr (ND != 1) g2_epilogue_landed(P);
     if (dbg && dbg_piece < 6 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 4 + 2 * dbg_piece] = g2_clock();
 
     // ---- the piece's result
@@ -682,7 +687,8 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
       {
         const int tid = opaque_tid();
         const int w = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
-        g2_epilogue_finish<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, P, m0, n0, w >> 1, w & 1, ln & 31, ln >> 5, osc, emb_line);   // (vec4 only: host-checked)
+        if constexpr (ND == 1) g2_epilogue_dense<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, m0, n0, w >> 1, w & 1, ln & 31, ln >> 5, osc);
+        else g2_epilogue_finish<G2_WM, G2_WN, G2_MI, G2_NI>(g, acc, P, m0, n0, w >> 1, w & 1, ln & 31, ln >> 5, osc, emb_line);   // (vec4 only: host-checked)
       }
     } else {
       // a middle / tail piece: publish the raw accumulators (lane-linear float4 slabs), write-through
@@ -732,12 +738,12 @@ __global__ void __launch_bounds__(512, 2) gconv3_kernel(const Gemm3Args A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int PREC, int WM, int NI>
+template <int PREC, int WM, int NI, int ND = 7>
 static int g3_launch(const Gemm3Args& A, hipStream_t st) {
   static bool attr_set[OFX_MAX_DEVICES] = {};
-  if (!ofx_raise_lds_limit(reinterpret_cast<const void*>(&gconv3_kernel<PREC, WM, NI>), G3Cfg<WM, NI>::LDS, attr_set))
+  if (!ofx_raise_lds_limit(reinterpret_cast<const void*>(&gconv3_kernel<PREC, WM, NI, ND>), G3Cfg<WM, NI>::LDS, attr_set))
     return OFX_ELAUNCH;
-  gconv3_kernel<PREC, WM, NI><<<A.G, G3Cfg<WM, NI>::THREADS, G3Cfg<WM, NI>::LDS, st>>>(A);
+  gconv3_kernel<PREC, WM, NI, ND><<<A.G, G3Cfg<WM, NI>::THREADS, G3Cfg<WM, NI>::LDS, st>>>(A);
   return OFX_OK;
 }
 
@@ -811,7 +817,7 @@ extern "C" int ofx_gconv3_plan(int64_t n_rows, int cout, int nkt, int wm, int ni
 // Returns OFX_OK (launched), a failure status, or 1 when the shape / workspace does not qualify (caller falls back
 // to the one-tile-per-block kernel).
 int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, size_t ws_tail_bytes, void* sync,
-                      size_t sync_bytes, hipStream_t st) {
+                      size_t sync_bytes, hipStream_t st, int nd) {
   G3Plan p;
   GemmArgs& g = a.e;
   if (!sync || ((uintptr_t)sync & 3) || !ws_tail || ((uintptr_t)ws_tail & 15)) return 1;
@@ -837,6 +843,13 @@ int ofx_launch_gconv3(Gemm2Args& a, int mode, int wm, int ni, void* ws_tail, siz
   // guarantees 16 B of readable slack behind nbr_ext, include/ofx.h)
   A.nbr_lim = (const char*)a.nbr_ext + ((((size_t)g.M * 28 - 4) >> 4) << 4);
   if (((uintptr_t)a.nbr_ext & 15)) return 1;
+  if (nd == 1) {                           // dense GEMM on the planes data path: pair modes, 128-column tiles only
+    if (ni != 2 || (mode != 2 && mode != 3)) return 1;
+#define G3_GO1(P_) (wm == 4 ? g3_launch<P_, 4, 2, 1>(A, st) : g3_launch<P_, 2, 2, 1>(A, st))
+    return mode == 2 ? G3_GO1(2) : G3_GO1(3);
+#undef G3_GO1
+  }
+  if (nd != 7) return 1;
 #define G3_GO(P_)                                                                                         \
   (ni == 1 ? (wm == 4 ? g3_launch<P_, 4, 1>(A, st) : g3_launch<P_, 2, 1>(A, st))                          \
            : (wm == 4 ? g3_launch<P_, 4, 2>(A, st) : g3_launch<P_, 2, 2>(A, st)))

@@ -148,6 +148,195 @@ __global__ void __launch_bounds__(512, KP == 64 ? 6 : 4) narrow_in_kernel(const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: the same operator driven by the branch-free gather table (nbr_ext, include/ofx.h) in a PERSISTENT, software-
+// pipelined block.  narrow_in_kernel's block is one chain of three dependent loads (segment bounds -> column -> x) followed
+// by its contraction and stores: 14 us per 64-row block at depth 8 with three blocks per CU -- latency, not bytes (954 us for
+// an 832 MB output; 0.22 of the HBM roof).  Here
+//   * a segment's source is ONE table entry (coalesced, 28 B per row) indexing ONE 32-B record (x + node type of a row, or
+//     the pre-averaged x mean + node-type counts of a multi-neighbour segment; narrow_rec_kernel writes them per call:
+//     32 B per id) -- a single memory sector per segment, no branch, no CSR walk;
+//   * a block walks row groups g, g + grid, ...: while the MFMAs and stores of group k run, the x pieces of group k + 1
+//     are in flight (their ids arrived during group k - 1) and the ids of group k + 2 are requested -- the chain is paid
+//     once per block, not once per 64 rows;
+//   * the wave's 32-column slice of W stays in registers for the whole block.
+struct NarrowIn2Args {
+  const float* x; int64_t ldx; int cin; int64_t N;
+  const int32_t* nbr_ext;                    // [N, 7]: < N row, N zero row, N + 1 + v aux record v + 1
+  const float* rec;                          // [N + 1 + V] records (narrow_rec_kernel): the id of the table IS the index
+  int nt;
+  const float* W; int cout; const float* bias;
+  float* out; int64_t ldc;
+  const int32_t* bid; float* stats_part; double* stats; int64_t stats_ld;
+  int64_t ngroups;
+};
+
+// One record per gatherable id, so that a segment's contribution is ONE aligned 32-B (cin <= 4) or 64-B (cin <= 8) piece
+// -- one memory sector per segment instead of a 12-B piece of x plus a node-type byte from another sector:
+//   [x (CI floats; the segment MEAN for an aux record) | node-type counts 0-3, 4-7 (2 x u32, one byte each) | 1 / count | pad]
+// ids < N: the node itself (count 1, one-hot type); N: zeros; N + v: the mean over multi-neighbour segment multi_seg[v - 1].
+template <int CI>
+__global__ void __launch_bounds__(256) narrow_rec_kernel(const float* __restrict__ x, int64_t ldx, int cin, int64_t N,
+                                                         const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ col,
+                                                         const int32_t* __restrict__ multi_seg, int64_t V,
+                                                         const uint8_t* __restrict__ ntype, int nt, float* __restrict__ rec) {
+  constexpr int RW = CI == 4 ? 8 : 16;                   // words per record
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i > N + V) return;
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+  unsigned t0 = 0, t1 = 0;
+  float inv = 0.f;
+  auto add = [&](int64_t j) {
+    const float* xr = x + j * ldx;
+#pragma unroll
+    for (int c = 0; c < CI; ++c) acc[c] += xr[c < cin ? c : cin - 1];
+    const int ty = nt ? (int)ntype[j] : 0;
+    if (ty < 4) t0 += 1u << (8 * ty); else t1 += 1u << (8 * (ty - 4));
+  };
+  if (i < N) {
+    add(i);
+    inv = 1.f;
+  } else if (i > N) {
+    const int64_t sgm = multi_seg[i - N - 1];
+    const int32_t b = seg_ptr[sgm], e = seg_ptr[sgm + 1];
+    for (int32_t p = b; p < e; ++p) add(col[p]);
+    inv = __frcp_rn((float)(e - b > 1 ? e - b : 1));
+#pragma unroll
+    for (int c = 0; c < CI; ++c) acc[c] *= inv;
+  }
+#pragma unroll
+  for (int c = 0; c < CI; ++c) acc[c] = c < cin ? acc[c] : 0.f;
+  float4* o = reinterpret_cast<float4*>(rec + i * RW);
+  o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  if (CI == 4) {
+    o[1] = make_float4(__uint_as_float(t0), __uint_as_float(t1), inv, 0.f);
+  } else {
+    o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    o[2] = make_float4(__uint_as_float(t0), __uint_as_float(t1), inv, 0.f);
+  }
+}
+
+template <int KP, int CI>
+__global__ void __launch_bounds__(512, KP <= 72 ? 4 : 2) narrow_in2_kernel(const NarrowIn2Args a) {
+  constexpr int LD = KP + 1;
+  __shared__ float cd[2][64 * LD];
+  __shared__ float red[8][32][2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cin = a.cin, nt = a.nt, cpd = cin + nt, K = 7 * cpd;
+  const bool wide = a.cout == 128;
+  const int slice = wide ? (wv & 3) : (wv & 1);
+  const int mt0 = wide ? (wv >> 2) : ((wv >> 1) & 1), nmt = (wide || wv < 4) ? 1 : 0;
+  const int ln = lane & 31, lk = lane >> 5;
+  const int64_t N = a.N;
+  // this thread's segment of every group: (row r of the group, direction); threads 448..511 have none
+  const bool seg = tid < 64 * 7;
+  const int r = tid / 7, dir = tid - r * 7;
+  // columns K .. KP - 1 of both stages are zero for the whole launch
+  for (int i = tid; i < 2 * 64 * (KP - K); i += 512) {
+    const int st = i / (64 * (KP - K)), q = i - st * (64 * (KP - K));
+    cd[st][(q / (KP - K)) * LD + K + q % (KP - K)] = 0.f;
+  }
+  // the wave's slice of W as the MFMA's B operand, for every group of this block
+  float bw[KP / 2];
+#pragma unroll
+  for (int kk = 0; kk < KP / 2; ++kk) {
+    const int k = 2 * kk + lk;
+    const float v = a.W[(int64_t)(k < K ? k : K - 1) * a.cout + slice * 32 + ln];
+    bw[kk] = k < K ? v : 0.f;
+  }
+  const float bias = a.bias ? a.bias[slice * 32 + ln] : 0.f;
+
+  const int Ni = (int)N;                                  // (ids are int32: N + 1 + V < 2^31, host-checked)
+  auto load_id = [&](int64_t g) -> int {
+    const int64_t row = g * 64 + r;
+    return (seg && g < a.ngroups && row < N) ? a.nbr_ext[row * 7 + dir] : Ni;               // (N = the zero record)
+  };
+  // what a segment contributes: CI floats of x (a mean for an aux record), packed node-type counts, 1 / count
+  struct Piece { float v[CI]; unsigned t0, t1; float inv; };
+  constexpr int RW = CI == 4 ? 8 : 16;
+  auto load_piece = [&](int id, Piece& P) {
+    const float4* ar = reinterpret_cast<const float4*>(a.rec + (int64_t)id * RW);
+    const float4 q0 = ar[0], qt = ar[CI == 4 ? 1 : 2];
+    P.v[0] = q0.x; P.v[1] = q0.y; P.v[2] = q0.z; P.v[3] = q0.w;
+    if constexpr (CI > 4) {
+      const float4 q1 = ar[1];
+      P.v[4] = q1.x; P.v[5] = q1.y; P.v[6] = q1.z; P.v[7] = q1.w;
+    }
+    P.t0 = __float_as_uint(qt.x); P.t1 = __float_as_uint(qt.y); P.inv = qt.z;
+  };
+  auto store_piece = [&](float* cdb, const Piece& P) {
+    if (!seg) return;
+    float* o = cdb + r * LD + dir * cpd;
+#pragma unroll
+    for (int c = 0; c < CI; ++c)
+      if (c < cin) o[c] = P.v[c];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (t < nt) o[cin + t] = (float)(((t < 4 ? P.t0 : P.t1) >> (8 * (t & 3))) & 255u) * P.inv;
+  };
+
+  const int64_t G = gridDim.x;
+  int64_t g = blockIdx.x;
+  Piece P;
+  int id_next;
+  {
+    const int id0 = load_id(g);
+    load_piece(id0, P);
+    id_next = load_id(g + G);
+  }
+  for (int it = 0; g < a.ngroups; g += G, ++it) {
+    float* cdb = cd[it & 1];
+    store_piece(cdb, P);                      // (waits for the pieces of this group: requested one group ago)
+    // do all rows of the group belong to one batch element?
+    const int64_t row0 = g * 64;
+    bool same = true;
+    if (a.stats && tid < 64 && row0 + tid < N) same = a.bid[row0 + tid] == a.bid[row0];
+    const bool uni = __syncthreads_and(same);
+    // next group's pieces (ids arrived during the previous group) and the ids after them: in flight under the MFMAs / stores
+    load_piece(id_next, P);
+    id_next = load_id(g + 2 * G);
+    float s_ = 0.f, q_ = 0.f;
+    for (int t = 0; t < nmt; ++t) {
+      const int mt = mt0 + t;
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float* ap = &cdb[(mt * 32 + ln) * LD + lk];
+#pragma unroll
+      for (int kk = 0; kk < KP / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk], bw[kk], acc, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t row = row0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk;
+        const float v = acc[i] + bias;
+        if (row < N) {
+          a.out[row * a.ldc + slice * 32 + ln] = v;
+          if (a.stats) {
+            if (uni) { s_ += v; q_ += v * v; }
+            else {
+              double* so = a.stats + ((int64_t)a.bid[row] * a.stats_ld + slice * 32 + ln) * 2;
+              unsafeAtomicAdd(so, (double)v);
+              unsafeAtomicAdd(so + 1, (double)v * (double)v);
+            }
+          }
+        }
+      }
+    }
+    if (a.stats) {
+      s_ += __shfl_xor(s_, 32);
+      q_ += __shfl_xor(q_, 32);
+      if (lk == 0) { red[wv][ln][0] = s_; red[wv][ln][1] = q_; }
+      __syncthreads();
+      if (tid < a.cout) {
+        const int sl = tid >> 5, j = tid & 31, o = wide ? 4 : 2;
+        *reinterpret_cast<float2*>(a.stats_part + (g * a.cout + tid) * 2) =
+            make_float2(red[sl][j][0] + red[sl + o][j][0], red[sl][j][1] + red[sl + o][j][1]);
+      }
+    }
+  }
+}
+
 struct NarrowOutArgs {
   const float* P; int64_t ldp; int cout; int64_t N;
   const int32_t* seg_ptr; const int32_t* col;
@@ -267,6 +456,50 @@ extern "C" int ofx_graphconv_narrow_in(const float* x, int64_t ldx, int cin, int
   const unsigned nb = (unsigned)nblk;
   if (K <= 64) { if (cin <= 4) narrow_in_kernel<64, 4><<<nb, 512, 0, st>>>(a); else narrow_in_kernel<64, 8><<<nb, 512, 0, st>>>(a); }
   else { if (cin <= 4) narrow_in_kernel<96, 4><<<nb, 512, 0, st>>>(a); else narrow_in_kernel<96, 8><<<nb, 512, 0, st>>>(a); }
+  OFX_LAUNCH_CHECK();
+  if (stats) {
+    GemmArgs g = {};
+    g.M = n_nodes; g.N = cout; g.bid = batch_id; g.stats = stats; g.stats_ld = stats_ld; g.stats_part = (float*)ws;
+    return ofx_launch_stats_reduce(g, 64, st);
+  }
+  return OFX_OK;
+}
+
+// The same convolution through the gather table (round 6, narrow_in2_kernel above).  nbr_ext / multi_seg / n_multi: the
+// branch-free table of the graph depth (ofx_graph_primary_ext); aux: scratch of (n_nodes + n_multi + 1) * (cin <= 4 ? 32 : 64)
+// bytes, 16-B aligned (one record per gatherable id).
+extern "C" int ofx_graphconv_narrow_in_tab(const float* x, int64_t ldx, int cin, int64_t n_nodes, const int32_t* seg_ptr,
+                                           const int32_t* col, const int32_t* nbr_ext, const int32_t* multi_seg,
+                                           int64_t n_multi, void* aux, const uint8_t* node_type, int nt, const float* W,
+                                           int cout, const float* bias, const int32_t* batch_id, float* out, int64_t ldc,
+                                           double* stats, int64_t stats_ld, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !seg_ptr || !col || !nbr_ext || !aux || ((uintptr_t)aux & 15) || n_multi < 0 || (n_multi > 0 && !multi_seg) || !W ||
+      !out || cin < 1 || cin > 8 || ldx < cin || nt < 0 || nt > 8 || (nt > 0 && !node_type) || (cout != 64 && cout != 128) ||
+      ldc < cout || n_nodes < 0 || 7 * (cin + nt) > 96 || n_nodes + 1 + n_multi >= (1ll << 31))
+    return OFX_EINVAL;
+  if (n_nodes == 0) return OFX_OK;
+  const int64_t ngroups = ofx_cdiv(n_nodes, 64);
+  if (stats && (!batch_id || stats_ld < cout || !ws || ws_bytes < (size_t)ngroups * cout * 2 * sizeof(float))) return OFX_EINVAL;
+  hipStream_t st = ofx_stream(stream);
+  const unsigned nab = (unsigned)ofx_cdiv(n_nodes + n_multi + 1, 256);
+  if (cin <= 4) narrow_rec_kernel<4><<<nab, 256, 0, st>>>(x, ldx, cin, n_nodes, seg_ptr, col, multi_seg, n_multi, node_type, nt, (float*)aux);
+  else narrow_rec_kernel<8><<<nab, 256, 0, st>>>(x, ldx, cin, n_nodes, seg_ptr, col, multi_seg, n_multi, node_type, nt, (float*)aux);
+  OFX_LAUNCH_CHECK();
+  NarrowIn2Args a = {x, ldx, cin, n_nodes, nbr_ext, (const float*)aux, nt, W, cout, bias, out, ldc,
+                     batch_id, (float*)ws, stats, stats_ld, ngroups};
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+  }
+  const int64_t want = (int64_t)cus * 2;                 // two 512-thread blocks per CU
+  const unsigned nb = (unsigned)(ngroups < want ? ngroups : want);
+  const int K = 7 * (cin + nt);
+  // (K = 70 -- three channels + seven node types, the depth-8 input convolution of the feature net -- gets its own width:
+  // 36 weight registers instead of 48 keep the block at four waves per SIMD without scratch)
+  if (K <= 64) { if (cin <= 4) narrow_in2_kernel<64, 4><<<nb, 512, 0, st>>>(a); else narrow_in2_kernel<64, 8><<<nb, 512, 0, st>>>(a); }
+  else if (K <= 72) { if (cin <= 4) narrow_in2_kernel<72, 4><<<nb, 512, 0, st>>>(a); else narrow_in2_kernel<72, 8><<<nb, 512, 0, st>>>(a); }
+  else { if (cin <= 4) narrow_in2_kernel<96, 4><<<nb, 512, 0, st>>>(a); else narrow_in2_kernel<96, 8><<<nb, 512, 0, st>>>(a); }
   OFX_LAUNCH_CHECK();
   if (stats) {
     GemmArgs g = {};

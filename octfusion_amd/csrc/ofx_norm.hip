@@ -565,15 +565,26 @@ extern "C" int ofx_gn_apply_planes(const float* x, int64_t ldx, int64_t n, int C
 // from x by extra blocks behind the main blocks, through a host-flattened source list (left_head / left_src).
 // The value summed for an aux row is the value a reader of the stored planes sees (hi + lo, not the unsplit fp32), so
 // the rows equal the stand-alone pre-pass of the planes GraphConv (planes_multi_mean_kernel) bit for bit.
+// Pair modes: the two lanes that hold the eight channels 8 p .. 8 p + 7 of a row (lane parity = parity of the float4 slot:
+// C / 4 is even) swap halves through a DPP quad permute, so that the even lane stores the 16 B of hi words and the odd
+// lane the 16 B of lo words: ONE 16-B store per lane and row, whole 128-B lines per wave instruction, instead of two 8-B
+// stores that each touch half of every line.  Callers keep both lanes of a pair on the same path (the row / octet / entry
+// conditions are uniform over the lanes of a row).
 template <int MODE>
 __device__ __forceinline__ float4 gn_store_planes(char* orow, int c, const float4& y) {
   if (MODE == 2 || MODE == 3) {
     unsigned h0, h1, l0, l1;
     g2_split2(MODE, y.x, y.y, h0, l0);
     g2_split2(MODE, y.z, y.w, h1, l1);
-    char* o = orow + (c >> 5) * 128 + (c & 31) * 2;
-    *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(o + 64) = make_uint2(l0, l1);
+    const bool odd = (c & 4) != 0;
+    // what the partner needs: the even lane's lo words, the odd lane's hi words
+    const unsigned s0 = odd ? h0 : l0, s1 = odd ? h1 : l1;
+    const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+    const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xF, 0xF, true);
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 o = odd ? u4{r0, r1, l0, l1} : u4{h0, h1, r0, r1};
+    // even lane: hi words of channels c .. c + 7 at the line's first half; odd lane: lo words of c - 4 .. c + 3 at its second
+    *reinterpret_cast<u4*>(orow + (c >> 5) * 128 + ((c & 24) * 2) + (odd ? 64 : 0)) = o;
     float4 j;
     g2_join2(MODE, h0, l0, j.x, j.y);
     g2_join2(MODE, h1, l1, j.z, j.w);

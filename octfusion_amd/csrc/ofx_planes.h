@@ -468,3 +468,44 @@ __device__ __forceinline__ void g2_epilogue_finish(const GemmArgs& g, f32x16 (&a
   }
 #undef OFX_RED
 }
+
+// Epilogue of the dense GEMM on the planes data path (gconv3_kernel<..., ND = 1>): out = acc * oscale + bias, written as
+// fp32 rows or as hi / lo pair planes (GemmArgs::out_planes) -- no residual, embedding or statistics, hence no request
+// phase and none of its 73 registers.  Same lane -> element mapping as g2_epilogue_finish.
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void g2_epilogue_dense(const GemmArgs& g, f32x16 (&acc)[MI][NI], int64_t m0, int64_t n0, int wm,
+                                                  int wn, int l31, int h, float osc) {
+  const int q = l31 & 3, k = l31 >> 2;
+  const bool q0 = q & 1, q1 = q & 2;
+  const int64_t mw = m0 + wm * MI * 32;
+  float4 bv[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
+    n = n < g.N ? n : g.N - 4;
+    bv[j] = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : f4zero();
+  }
+  const int pm = g.out_planes;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int64_t n = n0 + (wn * NI + j) * 32 + 4 * k;
+    const bool ncol = n < g.N;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float4 t[4];
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {                         // every lane takes part in the transposes
+        float v0 = acc[i][j][4 * G], v1 = acc[i][j][4 * G + 1], v2 = acc[i][j][4 * G + 2], v3 = acc[i][j][4 * G + 3];
+        quad_transpose(v0, v1, v2, v3, q0, q1);
+        t[G] = make_float4(fmaf(v0, osc, bv[j].x), fmaf(v1, osc, bv[j].y), fmaf(v2, osc, bv[j].z), fmaf(v3, osc, bv[j].w));
+      }
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {
+        const int64_t m = mw + i * 32 + q + 4 * h + 8 * G;
+        if (m >= g.M || !ncol) continue;
+        if (pm) ofx_store_planes4(g.out, m * g.ldc + n, t[G], pm);
+        else __builtin_nontemporal_store(g2_v4f{t[G].x, t[G].y, t[G].z, t[G].w}, reinterpret_cast<g2_v4f*>(g.out + m * g.ldc + n));
+      }
+    }
+  }
+}

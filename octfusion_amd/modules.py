@@ -96,7 +96,8 @@ class GraphConv(nn.Module):
             if ops.narrow_in_ok(self.in_channels, self.out_channels, nt):
                 y = ops.graphconv_narrow_in(x, seg_ptr, col, self.weights, self.in_channels, nt,
                                             doctree.node_type8(d) if nt else None, self.bias if self.use_bias else None,
-                                            doctree.batch_id32(d) if stats is not None else None, out, stats)
+                                            doctree.batch_id32(d) if stats is not None else None, out, stats,
+                                            ext=doctree.ext(d))
                 if stats is not None:
                     setattr(y, ops.STATS_ATTR, stats)
                 return y
@@ -314,6 +315,7 @@ class Upsample(nn.Module):
         self.weights = nn.Parameter(torch.empty(channels, channels, 8))
         nn.init.xavier_uniform_(self.weights)
         self._pw = ops.PackedWeight()
+        self._pgp = ops.PackedGemmPlanes()
 
     def packed(self):
         # x @ W.flatten(1): plain [K=C, N=8C]
@@ -321,6 +323,19 @@ class Upsample(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, a_rows=None, out=None, out_planes=0):
+        C = self.channels
+        mode = ops.planes_mode()
+        if (ops.GEMM_PLANES and out is not None and a_rows is not None and ops.planes_pairs(mode) and out_planes == mode
+                and C % 32 == 0 and C >= 256 and a_rows.numel() >= 256):
+            # the unpool GEMM on the data path of the planes GraphConv (ofx_gemm_planes): the rows to unpool are gathered and
+            # split into operand planes (M x C: a few MB), the [M, C] x [C, 8 C] product runs on the persistent LDS-DMA
+            # kernel and its epilogue writes the children's rows as the planes the following GraphConv gathers
+            M = a_rows.numel()
+            xa = torch.empty(M, C, dtype=torch.float32, device=x.device)
+            ops.rows_copy(x, xa, M, smap=a_rows, planes=mode)
+            setattr(xa, ops.PLANES_ATTR, mode)
+            if ops.gemm_planes(xa, self._pgp.get(self.weights.view(C, C * 8), mode), out, out_planes):
+                return out
         y = ops.gemm(x, self.packed(), out=out, a_rows=a_rows, out_planes=out_planes)
         return y.view(-1, self.channels) if out is None else out
 

@@ -530,6 +530,78 @@ def gather_gemm(x, tab, ntap, pw, n_out, bias=None, res=None, out=None, out_rows
     return out
 
 
+# the unpool GEMM on the planes data path (ofx_gemm_planes).  Built in round 6 and measured at parity with the register-staged
+# kernel it was to replace (tools/gemm_planes_probe.py: 94.0 vs 94.5 us at [4976, 512] x [512, 4096], 128 vs 118 us at
+# [21344, 256] x [256, 2048], 390 vs 402 us at [71088, 256] x [256, 2048] incl. the 10-23 us gather + split of its input rows):
+# off by default, kept for the A/B (OFX_GEMM_PLANES=1)
+GEMM_PLANES = os.environ.get('OFX_GEMM_PLANES', '0') == '1'
+_ROW_TAB = {}
+
+
+class PackedGemmPlanes:
+    """Dense weights [K, N] packed for ofx_gemm_planes (cached per parameter version and mode)."""
+
+    def __init__(self):
+        self.t = None
+        self.key = None
+
+    def get(self, w2d, mode):
+        """w2d: a [K, N] VIEW of the parameter (any strides)."""
+        key = (w2d.data_ptr(), w2d._version, tuple(w2d.shape), tuple(w2d.stride()), mode)
+        if key != self.key:
+            _chk(w2d)
+            K, N = w2d.shape
+            nb = _lib.lib().ofx_gemm_planes_packed_bytes(K, N, mode)
+            assert nb > 0
+            t = torch.empty(nb, dtype=torch.uint8, device=w2d.device)
+            assert t.data_ptr() % 128 == 0
+            call('ofx_pack_gemm_planes', ptr(w2d.detach()), w2d.stride(0), w2d.stride(1), K, N, mode, ptr(t), stream())
+            self.t, self.key, self.K, self.N = t, key, K, N
+        return self
+
+
+def gemm_planes(a_planes, pgp, out, out_planes=0, bias=None):
+    """out = a_planes @ W on the planes GraphConv's data path (ofx_gemm_planes; a_planes: pair planes [M, K], row m of the
+    output from row m of the input).  Returns False when the shape does not qualify (nothing launched)."""
+    mode = planes_of(a_planes)
+    M, K = a_planes.shape
+    assert planes_pairs(mode) and K == pgp.K and a_planes.stride(1) == 1
+    out2, ldc = _row_major(out)
+    assert out2 is out
+    dev = a_planes.device
+    key = (dev.index, M)
+    tab = _ROW_TAB.get(key)
+    if tab is None:
+        if len(_ROW_TAB) > 64:
+            _ROW_TAB.clear()
+        _no_capture('the row table of a dense planes GEMM')
+        tab = torch.zeros(M * 7 + 4, dtype=torch.int32, device=dev)
+        tab[:M * 7].view(M, 7)[:, 0] = torch.arange(M, dtype=torch.int32, device=dev)
+        _ROW_TAB[key] = tab
+    ws = workspace(dev)
+    sync = sync_words(dev)
+    _meta('dense_gemm', 2.0 * M * K * pgp.N, 4.0 * (M * K + K * pgp.N + M * pgp.N), (M, K, pgp.N, 'planes'))
+    prof = _lib.PROFILE
+    lib = _lib.lib()
+    args = (ptr(a_planes), a_planes.stride(0) * 4, M, M, K, ptr(tab), ptr(pgp.t), pgp.N, ptr(bias), ptr(out), ldc, out_planes,
+            ptr(ws), ws.numel(), ptr(sync), sync.numel() * 4, mode, stream())
+    if prof is not None:
+        meta, _lib.META = _lib.META, None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = lib.ofx_gemm_planes(*args)
+        e1.record()
+        if rc == 0:
+            prof.append(('ofx_gemm_planes', e0, e1, meta))
+    else:
+        _lib.META = None
+        rc = lib.ofx_gemm_planes(*args)
+    if rc < 0:
+        raise _lib.OfxError('ofx_gemm_planes failed with status %d' % rc)
+    return rc == 0
+
+
 LINEAR_SMALL = True          # A/B switch: False sends the few-row linears through the MFMA GEMM again
 
 
@@ -644,9 +716,19 @@ def narrow_in_ok(cin, cout, nt):
     return NARROW_IN and cin <= 8 and cout in (64, 128) and 7 * (cin + nt) <= 96
 
 
-def graphconv_narrow_in(x, seg_ptr, col, weights, cin, nt, node_type=None, bias=None, batch_id=None, out=None, stats=None):
+# the table-driven, persistent, pipelined launch of the input convolution (ofx_graphconv_narrow_in_tab).  Measured (tools/
+# narrow_in_probe.py): depth 8 (3.25 M rows) 920 -> 640 us; depth 7 (0.71 M) 147 -> 153 us; depth 6 (0.22 M) 75 -> 82 us -- its
+# record pre-pass and the two-blocks-per-CU persistent grid only pay on long tensors, so it takes the launches from
+# NARROW_IN_TAB_MIN_ROWS rows up (OFX_NARROW_IN_TAB=0: never)
+NARROW_IN_TAB = os.environ.get('OFX_NARROW_IN_TAB', '1') == '1'
+NARROW_IN_TAB_MIN_ROWS = int(os.environ.get('OFX_NARROW_IN_TAB_MIN_ROWS', str(1 << 20)))
+
+
+def graphconv_narrow_in(x, seg_ptr, col, weights, cin, nt, node_type=None, bias=None, batch_id=None, out=None, stats=None,
+                        ext=None):
     """The U-Net's INPUT GraphConv (3 / 8 channels -> 64 / 128): gather + exact-fp32 FMA with the weights in registers
-    (ofx_graphconv_narrow_in).  weights: the raw nn.Parameter [7 * (cin + nt), cout]; node_type: uint8 [N]."""
+    (ofx_graphconv_narrow_in).  weights: the raw nn.Parameter [7 * (cin + nt), cout]; node_type: uint8 [N].
+    ext = (nbr_ext, multi_seg, n_multi): the branch-free gather table -> the persistent, pipelined launch."""
     x, ldx = _row_major(x)
     w = weights.detach()
     if not w.is_contiguous():
@@ -674,9 +756,16 @@ def graphconv_narrow_in(x, seg_ptr, col, weights, cin, nt, node_type=None, bias=
     flops = 2.0 * N * w.shape[0] * cout
     nbytes = 4.0 * (E * cin + N * cout + w.numel()) + 8.0 * E
     _meta('graphconv_narrow', flops, nbytes, (N, cin, cout, 'narrow_in'))
-    call('ofx_graphconv_narrow_in', ptr(x), ldx, cin, N, ptr(seg_ptr), ptr(col), ptr(node_type) if nt else None, nt,
-         ptr(w), cout, ptr(bias), ptr(batch_id) if stats is not None else None, ptr(out), ldc, ptr(stats), cout,
-         ptr(ws), ws.numel(), stream())
+    if ext is not None and NARROW_IN_TAB and N >= NARROW_IN_TAB_MIN_ROWS:
+        nbr_ext, multi_seg, n_multi = ext
+        aux = torch.empty((N + n_multi + 1) * (8 if cin <= 4 else 16), dtype=torch.float32, device=x.device)
+        call('ofx_graphconv_narrow_in_tab', ptr(x), ldx, cin, N, ptr(seg_ptr), ptr(col), ptr(nbr_ext), ptr(multi_seg), n_multi,
+             ptr(aux), ptr(node_type) if nt else None, nt, ptr(w), cout, ptr(bias),
+             ptr(batch_id) if stats is not None else None, ptr(out), ldc, ptr(stats), cout, ptr(ws), ws.numel(), stream())
+    else:
+        call('ofx_graphconv_narrow_in', ptr(x), ldx, cin, N, ptr(seg_ptr), ptr(col), ptr(node_type) if nt else None, nt,
+             ptr(w), cout, ptr(bias), ptr(batch_id) if stats is not None else None, ptr(out), ldc, ptr(stats), cout,
+             ptr(ws), ws.numel(), stream())
     if prof is not None:
         e1.record()
         prof.append((e0, e1, flops, nbytes, cout, ('graph', N, cin, cout)))

@@ -91,7 +91,9 @@ def test_planes_kernels_have_no_scratch():
         return len(rows), bad
     with ThreadPoolExecutor(2) as ex:
         res = list(ex.map(audit, ['ofx_gemm3.hip', 'ofx_gemm2.hip']))
-    assert res[0][0] == 12 and res[1][0] == 12, res        # 3 contraction modes x 2 geometries x 2 tile widths each
+    # gconv3: 3 contraction modes x 2 geometries x 2 tile widths + the dense-GEMM instantiations (ND = 1: 2 pair modes x 2
+    # geometries); gconv2: 3 x 2 x 2
+    assert res[0][0] == 16 and res[1][0] == 12, res
     assert not res[0][1] and not res[1][1], res
 
 

@@ -79,6 +79,32 @@ def test_three_stage_cascade_vs_oracle():
     replayed in the oracle ON THE PRODUCT'S OWN STEP INPUT.  (A whole-loop comparison is meaningless here: with
     random weights the tiny nets are chaotic -- a 1e-5 perturbation of the initial noise flips 43 % of the signs of the
     ORACLE's own lr result after 4 steps -- so the steps are checked one by one.)"""
+    worst = _three_stage_cascade(1e-3)
+    print('cascade per-call rel-to-max errors vs oracle:', worst)
+
+
+def test_cascade_in_fp16_single_pass():
+    """BASELINE configs[4] ("depth-8/6/4 cascade ... fp16 MFMA"): the same three-stage cascade with the planes GraphConv
+    in its single-pass fp16 mode (`ops.set_precision('fp16')`: one v_mfma_f32_32x32x16_f16 per product, activations and
+    weights rounded to fp16; every other contraction in bf16 pairs), every denoiser call against the fp32 oracle.
+    STATED BOUND: 2e-2 rel-to-max per call (measured here: ~1e-3 ... 6e-3; at the real widths the whole feature step
+    reads 6.2e-4 rel-to-max and 2e-2 element-wise p99.9) -- reduced precision by construction, which
+    is why the shipped default of every stage, cfg5 included, is fp16x3."""
+    from octfusion_amd import ops
+    saved = (ops.get_precision(), ops.PLANES_MIN_TILES)
+    ops.set_precision('fp16')
+    ops.PLANES_MIN_TILES = 1                       # the tiny fixture layers must take the planes kernel too
+    try:
+        worst = _three_stage_cascade(2e-2)
+    finally:
+        ops.set_precision(saved[0])
+        ops.PLANES_MIN_TILES = saved[1]
+    print('fp16 single-pass cascade, per-call rel-to-max errors vs oracle:', worst)
+    from test_gpu_fullwidth import report
+    report(dict(test='cascade_fp16_single_pass', bound=2e-2, **{'rel_to_max_' + k: v for k, v in worst.items()}))
+
+
+def _three_stage_cascade(tol):
     from octfusion_amd import pipeline, sampler
     from octfusion_amd.dual_octree import DualOctree
     from octfusion_amd.graph_unet_union import UNet3DModel
@@ -166,9 +192,9 @@ def test_three_stage_cascade_vs_oracle():
             nxt = rec.calls[k + 1]['xsc']
             if stage == 'lr':
                 assert nxt is not None and rel(nxt, out) < 1e-6
-    print('cascade per-call rel-to-max errors vs oracle:', worst, '(N5 %d, N7 %d)' % (n5, n7))
     for stage, e in worst.items():
-        assert e < 1e-3, (stage, e)
+        assert e < tol, (stage, e)
+    return worst
 
 
 def test_two_stage_seeding_is_reproducible_and_reference_ordered():

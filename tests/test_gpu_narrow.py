@@ -31,7 +31,8 @@ def _trees():
 
 
 @pytest.mark.parametrize('cin,cout,d,nt,bias', [(3, 128, 5, 4, False), (8, 128, 5, 4, True), (3, 64, 4, 3, True),
-                                                (4, 128, 5, 0, False), (8, 64, 5, 4, False)])
+                                                (4, 128, 5, 0, False), (8, 64, 5, 4, False), (3, 64, 5, 7, False),
+                                                (4, 128, 5, 8, True)])
 def test_narrow_input_conv(cin, cout, d, nt, bias):
     from octfusion_amd import modules as M, ops
     from oracle import modules as OM
@@ -46,6 +47,7 @@ def test_narrow_input_conv(cin, cout, d, nt, bias):
     ref = OM.graph_conv(x.double(), o_doc, d, sd['weights'].double(), sd['bias'].double() if bias else None, nt)
     assert ops.narrow_in_ok(cin, cout, nt if nt > 1 else 0)
     wide = torch.full((N, cout + 64), 7.0, device=dev())
+    ops.NARROW_IN_TAB_MIN_ROWS = 0                    # the table-driven launch at any size (product: from 1 M rows up)
     with ops.stats_scope(dev()):
         y = conv(x.to(dev()), doc, d, out=wide[:, 64:])
         st = ops.get_stats(y)
@@ -59,6 +61,16 @@ def test_narrow_input_conv(cin, cout, d, nt, bias):
             want[:, :, 0].index_add_(0, bid, y.double())
             want[:, :, 1].index_add_(0, bid, y.double() ** 2)
             assert float((st.view(B, cout, 2) - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    # the CSR-walking launch of round 5 (one block per 64 rows) against the table-driven persistent one (the default)
+    ops.NARROW_IN_TAB = False
+    try:
+        with ops.stats_scope(dev()):
+            y_csr = conv(x.to(dev()), doc, d)
+    finally:
+        ops.NARROW_IN_TAB = True
+        ops.NARROW_IN_TAB_MIN_ROWS = 1 << 20
+    assert errors(y_csr, ref)['rel_to_max'] < 2e-6
+    assert float((y_csr - y).abs().max()) <= 2e-6 * float(ref.abs().max())
     # A/B: the contraction path it replaces gives the same operator
     ops.NARROW_IN = False
     try:

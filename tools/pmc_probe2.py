@@ -12,12 +12,15 @@ from octfusion_amd.dual_octree import DualOctree
 from octfusion_amd.octree import split2octree_small
 
 LAYER_SETS = {'hr': [(6, 128, 128), (5, 256, 256), (6, 384, 128), (5, 512, 512)],
+              # the same four layers at the hr_cond workload's own size (shell-6 x 4, N6 = 108 504): VERDICT r05 weak #6c
+              'hr_cond': [(6, 128, 128), (5, 256, 256), (6, 384, 128), (5, 512, 512)],
               # the two dominant layers of the Objaverse feature stage (shell-8 x 8, N8 = 3 248 400): VERDICT r04 item 5
               'feature': [(8, 64, 64), (8, 128, 64)]}
 which = sys.argv[1] if len(sys.argv) > 1 else 'hr'
 dev = torch.device('cuda:0')
 torch.set_grad_enabled(False)
-oc = split2octree_small(synthetic.shell6_split(8, jitter=True).to(dev), 6, 4)
+BATCH = 4 if which == 'hr_cond' else 8
+oc = split2octree_small(synthetic.shell6_split(BATCH, jitter=True).to(dev), 6, 4)
 if which == 'feature':
     from octfusion_amd.octree import split2octree_large
     x6, y6, z6, _ = oc.xyzb(6)
@@ -32,7 +35,7 @@ for d, cin, cout in LAYER_SETS[which]:
     gn = M.DualOctreeGroupNorm(cin).to(dev)
     xp = gn(torch.randn(N, cin, device=dev), doc, d, act='silu', planes=ops.planes_mode())   # planes + aux rows (no pre-pass launch)
     res = torch.randn(N, cout, device=dev)
-    emb = torch.randn(8, cout, device=dev)
+    emb = torch.randn(BATCH, cout, device=dev)
     for _ in range(4):
         with ops.stats_scope(dev):
             conv(xp, doc, d, emb=emb, res=res)

@@ -18,8 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, out_path = sys.argv[1], sys.argv[2]
 which = sys.argv[3] if len(sys.argv) > 3 else 'hr'
 # order of tools/pmc_probe2.py <which>
-LAYERS = {'hr': [(6, 128, 128), (5, 256, 256), (6, 384, 128), (5, 512, 512)], 'feature': [(8, 64, 64), (8, 128, 64)]}[which]
-NODES = {6: 217008, 5: 67600, 8: 3248400}
+LAYERS = {'hr': [(6, 128, 128), (5, 256, 256), (6, 384, 128), (5, 512, 512)],
+          'hr_cond': [(6, 128, 128), (5, 256, 256), (6, 384, 128), (5, 512, 512)], 'feature': [(8, 64, 64), (8, 128, 64)]}[which]
+NODES = {6: 108504, 5: 33800} if which == 'hr_cond' else {6: 217008, 5: 67600, 8: 3248400}
 per = {}
 for f in glob.glob(os.path.join(src, '*', '*counter_collection.csv')):
     byd = {}
@@ -40,8 +41,8 @@ for f in ('ofx_gemm3.hip', 'ofx_planes.h', 'ofx_gemm2.hip', 'ofx_gemm.hip', 'ofx
     h.update(open(os.path.join(ROOT, 'octfusion_amd', 'csrc', f), 'rb').read())
 out = {'kernel_source_sha16': h.hexdigest()[:16], 'workload': which,
        'source': 'rocprofv3 --pmc, one pass per counter group, over tools/pmc_probe2.py on MI355X: 4 launches per layer '
-                 'of gconv3_kernel (persistent planes GraphConv, default fp16-pair instantiation, emb + residual + fused statistics epilogue), shell-6 B=8 (feature: shell-8 B=8); raw rows '
-                 'in profiles/r05/pmc_*_probe2*.csv',
+                 'of gconv3_kernel (persistent planes GraphConv, default fp16-pair instantiation, emb + residual + fused statistics epilogue), shell-6 B=8 (hr_cond: shell-6 B=4; feature: shell-8 B=8); raw rows '
+                 'in profiles/r06/pmc_*_probe2*.csv',
        'fetch_correction': 'HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB)',
        'clock_note': 'GRBM_GUI_ACTIVE is summed over the 8 XCDs: clock = counter / 8 / kernel duration', 'layers': []}
 for L in LAYERS:

@@ -175,40 +175,81 @@ struct NarrowIn2Args {
 // -- one memory sector per segment instead of a 12-B piece of x plus a node-type byte from another sector:
 //   [x (CI floats; the segment MEAN for an aux record) | node-type counts 0-3, 4-7 (2 x u32, one byte each) | 1 / count | pad]
 // ids < N: the node itself (count 1, one-hot type); N: zeros; N + v: the mean over multi-neighbour segment multi_seg[v - 1].
+// Two launches: the node records (a streaming copy: x row + node type -> one 32-B record; measured at 1 TB/s while it shared
+// a kernel, and its registers, with the CSR walk below) and the aux records (one thread per multi-neighbour segment).
 template <int CI>
-__global__ void __launch_bounds__(256) narrow_rec_kernel(const float* __restrict__ x, int64_t ldx, int cin, int64_t N,
-                                                         const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ col,
-                                                         const int32_t* __restrict__ multi_seg, int64_t V,
-                                                         const uint8_t* __restrict__ ntype, int nt, float* __restrict__ rec) {
-  constexpr int RW = CI == 4 ? 8 : 16;                   // words per record
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i > N + V) return;
+__global__ void __launch_bounds__(256) narrow_rec_nodes_kernel(const float* __restrict__ x, int64_t ldx, int cin, int64_t N,
+                                                               const uint8_t* __restrict__ ntype, int nt,
+                                                               float* __restrict__ rec) {
+  constexpr int RW = CI == 4 ? 8 : 16;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= N; i += (int64_t)gridDim.x * 256) {
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = 0.f;
+    unsigned t0 = 0, t1 = 0;
+    float inv = 0.f;
+    if (i < N) {                                          // (record N = the zero row)
+      const float* xr = x + i * ldx;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) v[c] = c < cin ? xr[c < cin ? c : 0] : 0.f;
+      const int ty = nt ? (int)ntype[i] : 0;
+      t0 = ty < 4 ? 1u << (8 * ty) : 0u;
+      t1 = ty < 4 ? 0u : 1u << (8 * (ty - 4));
+      inv = 1.f;
+    }
+    float4* o = reinterpret_cast<float4*>(rec + i * RW);
+    o[0] = make_float4(v[0], v[1], v[2], v[3]);
+    if (CI == 4) {
+      o[1] = make_float4(__uint_as_float(t0), __uint_as_float(t1), inv, 0.f);
+    } else {
+      o[1] = make_float4(v[4], v[5], v[6], v[7]);
+      o[2] = make_float4(__uint_as_float(t0), __uint_as_float(t1), inv, 0.f);
+    }
+  }
+}
+
+template <int CI>
+__global__ void __launch_bounds__(256) narrow_rec_aux_kernel(const float* __restrict__ x, int64_t ldx, int cin, int64_t N,
+                                                             const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ col,
+                                                             const int32_t* __restrict__ multi_seg, int64_t V,
+                                                             const uint8_t* __restrict__ ntype, int nt, float* __restrict__ rec) {
+  constexpr int RW = CI == 4 ? 8 : 16;
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;          // aux record v + 1 = id N + 1 + v
+  if (v >= V) return;
   float acc[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = 0.f;
   unsigned t0 = 0, t1 = 0;
-  float inv = 0.f;
-  auto add = [&](int64_t j) {
-    const float* xr = x + j * ldx;
+  const int64_t sgm = multi_seg[v];
+  const int32_t b = seg_ptr[sgm], e = seg_ptr[sgm + 1];
+  // groups of four neighbours with all column ids, then all x pieces and node types in flight together (a serial walk is
+  // a chain of two dependent loads per neighbour; segments hold 4 ... 16 of them)
+  for (int32_t p0 = b; p0 < e; p0 += 4) {
+    int64_t j[4];
 #pragma unroll
-    for (int c = 0; c < CI; ++c) acc[c] += xr[c < cin ? c : cin - 1];
-    const int ty = nt ? (int)ntype[j] : 0;
-    if (ty < 4) t0 += 1u << (8 * ty); else t1 += 1u << (8 * (ty - 4));
-  };
-  if (i < N) {
-    add(i);
-    inv = 1.f;
-  } else if (i > N) {
-    const int64_t sgm = multi_seg[i - N - 1];
-    const int32_t b = seg_ptr[sgm], e = seg_ptr[sgm + 1];
-    for (int32_t p = b; p < e; ++p) add(col[p]);
-    inv = __frcp_rn((float)(e - b > 1 ? e - b : 1));
+    for (int k = 0; k < 4; ++k) j[k] = col[p0 + k < e ? p0 + k : b];
+    float xv[4][CI];
+    int ty[4];
 #pragma unroll
-    for (int c = 0; c < CI; ++c) acc[c] *= inv;
+    for (int k = 0; k < 4; ++k) {
+      const float* xr = x + j[k] * ldx;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) xv[k][c] = xr[c < cin ? c : cin - 1];
+      ty[k] = nt ? (int)ntype[j[k]] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (p0 + k < e) {
+#pragma unroll
+        for (int c = 0; c < CI; ++c) acc[c] += xv[k][c];
+        if (ty[k] < 4) t0 += 1u << (8 * ty[k]); else t1 += 1u << (8 * (ty[k] - 4));
+      }
+    }
   }
+  const float inv = __frcp_rn((float)(e - b > 1 ? e - b : 1));
 #pragma unroll
-  for (int c = 0; c < CI; ++c) acc[c] = c < cin ? acc[c] : 0.f;
-  float4* o = reinterpret_cast<float4*>(rec + i * RW);
+  for (int c = 0; c < CI; ++c) acc[c] = c < cin ? acc[c] * inv : 0.f;
+  float4* o = reinterpret_cast<float4*>(rec + (N + 1 + v) * RW);
   o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
   if (CI == 4) {
     o[1] = make_float4(__uint_as_float(t0), __uint_as_float(t1), inv, 0.f);
@@ -481,9 +522,17 @@ extern "C" int ofx_graphconv_narrow_in_tab(const float* x, int64_t ldx, int cin,
   const int64_t ngroups = ofx_cdiv(n_nodes, 64);
   if (stats && (!batch_id || stats_ld < cout || !ws || ws_bytes < (size_t)ngroups * cout * 2 * sizeof(float))) return OFX_EINVAL;
   hipStream_t st = ofx_stream(stream);
-  const unsigned nab = (unsigned)ofx_cdiv(n_nodes + n_multi + 1, 256);
-  if (cin <= 4) narrow_rec_kernel<4><<<nab, 256, 0, st>>>(x, ldx, cin, n_nodes, seg_ptr, col, multi_seg, n_multi, node_type, nt, (float*)aux);
-  else narrow_rec_kernel<8><<<nab, 256, 0, st>>>(x, ldx, cin, n_nodes, seg_ptr, col, multi_seg, n_multi, node_type, nt, (float*)aux);
+  {
+    const int64_t nbn = ofx_cdiv(n_nodes + 1, 256);
+    const unsigned gn_ = (unsigned)(nbn < 16384 ? nbn : 16384);
+    if (cin <= 4) narrow_rec_nodes_kernel<4><<<gn_, 256, 0, st>>>(x, ldx, cin, n_nodes, node_type, nt, (float*)aux);
+    else narrow_rec_nodes_kernel<8><<<gn_, 256, 0, st>>>(x, ldx, cin, n_nodes, node_type, nt, (float*)aux);
+    if (n_multi > 0) {
+      const unsigned ga_ = (unsigned)ofx_cdiv(n_multi, 256);
+      if (cin <= 4) narrow_rec_aux_kernel<4><<<ga_, 256, 0, st>>>(x, ldx, cin, n_nodes, seg_ptr, col, multi_seg, n_multi, node_type, nt, (float*)aux);
+      else narrow_rec_aux_kernel<8><<<ga_, 256, 0, st>>>(x, ldx, cin, n_nodes, seg_ptr, col, multi_seg, n_multi, node_type, nt, (float*)aux);
+    }
+  }
   OFX_LAUNCH_CHECK();
   NarrowIn2Args a = {x, ldx, cin, n_nodes, nbr_ext, (const float*)aux, nt, W, cout, bias, out, ldc,
                      batch_id, (float*)ws, stats, stats_ld, ngroups};

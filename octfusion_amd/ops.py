@@ -717,11 +717,11 @@ def narrow_in_ok(cin, cout, nt):
 
 
 # the table-driven, persistent, pipelined launch of the input convolution (ofx_graphconv_narrow_in_tab).  Measured (tools/
-# narrow_in_probe.py): depth 8 (3.25 M rows) 920 -> 640 us; depth 7 (0.71 M) 147 -> 153 us; depth 6 (0.22 M) 75 -> 82 us -- its
-# record pre-pass and the two-blocks-per-CU persistent grid only pay on long tensors, so it takes the launches from
-# NARROW_IN_TAB_MIN_ROWS rows up (OFX_NARROW_IN_TAB=0: never)
+# narrow_in_probe.py, eager): depth 8 (3.25 M rows) 915 -> 588 us; depth 7 (0.71 M) 143 -> 138 us; depth 6 (0.22 M) 77 -> 81 us
+# (kernel time 75 -> 65 us, but its two record pre-pass launches cost more than that on a tensor this short), so it takes
+# the launches from NARROW_IN_TAB_MIN_ROWS rows up (OFX_NARROW_IN_TAB=0: never)
 NARROW_IN_TAB = os.environ.get('OFX_NARROW_IN_TAB', '1') == '1'
-NARROW_IN_TAB_MIN_ROWS = int(os.environ.get('OFX_NARROW_IN_TAB_MIN_ROWS', str(1 << 20)))
+NARROW_IN_TAB_MIN_ROWS = int(os.environ.get('OFX_NARROW_IN_TAB_MIN_ROWS', str(1 << 19)))
 
 
 def graphconv_narrow_in(x, seg_ptr, col, weights, cin, nt, node_type=None, bias=None, batch_id=None, out=None, stats=None,

@@ -47,7 +47,7 @@ def test_narrow_input_conv(cin, cout, d, nt, bias):
     ref = OM.graph_conv(x.double(), o_doc, d, sd['weights'].double(), sd['bias'].double() if bias else None, nt)
     assert ops.narrow_in_ok(cin, cout, nt if nt > 1 else 0)
     wide = torch.full((N, cout + 64), 7.0, device=dev())
-    ops.NARROW_IN_TAB_MIN_ROWS = 0                    # the table-driven launch at any size (product: from 1 M rows up)
+    ops.NARROW_IN_TAB_MIN_ROWS = 0                    # the table-driven launch at any size (product: from 512 k rows up)
     with ops.stats_scope(dev()):
         y = conv(x.to(dev()), doc, d, out=wide[:, 64:])
         st = ops.get_stats(y)
@@ -68,7 +68,7 @@ def test_narrow_input_conv(cin, cout, d, nt, bias):
             y_csr = conv(x.to(dev()), doc, d)
     finally:
         ops.NARROW_IN_TAB = True
-        ops.NARROW_IN_TAB_MIN_ROWS = 1 << 20
+        ops.NARROW_IN_TAB_MIN_ROWS = 1 << 19
     assert errors(y_csr, ref)['rel_to_max'] < 2e-6
     assert float((y_csr - y).abs().max()) <= 2e-6 * float(ref.abs().max())
     # A/B: the contraction path it replaces gives the same operator

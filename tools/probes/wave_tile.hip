@@ -7,7 +7,9 @@
 //      (48 KB per CU per step), three LDS stages, one s_barrier per step;
 //   B  the geometry asked for: 256 threads = 4 waves (1 per SIMD), wave tile 128 x 128 (MI 4, NI 4), block tile 256 x 256:
 //      per k-step per wave 96 MFMAs on 256 accumulator registers (AGPRs), 32 ds_read_b128, 16 global_load_lds x 1 KB
-//      (64 KB per CU per step = 2/3 of A's bytes per MFMA, half of its fragment reads per MFMA), two LDS stages.
+//      (64 KB per CU per step = 2/3 of A's bytes per MFMA, half of its fragment reads per MFMA), two LDS stages;
+//   C  4 waves with 128 x 64 wave tiles on today's block tile and stages;  D  8 waves (2 per SIMD) with 64 x 128 wave tiles on a
+//      256 x 256 block tile, two stages: B's DMA ratio, 0.5 reads per MFMA, two waves per SIMD to cover each other's waits.
 //
 // The DMA source is an L2-resident buffer (the best case for both); LDS reads of the next half step are issued under the
 // current half's MFMAs; the waits are hand-counted.  No epilogue, no gather misses, no tile switch: this is the ceiling of
@@ -183,6 +185,8 @@ int main() {
     go<8, 2, 2, 3, 49152, 6, false, true>("A  8 waves, 64 x 64 wave tiles, 48 KB DMA / step", cus, 4000, src, mask);
     go<4, 4, 4, 2, 65536, 16, true, true>("B  4 waves, 128 x 128 wave tiles (AGPR acc), 64 KB DMA / step", cus, 2000, src, mask);
     go<4, 4, 2, 3, 49152, 12, true, true>("C  4 waves, 128 x 64 wave tiles (AGPR acc), 48 KB DMA / step", cus, 4000, src, mask);
+    go<8, 2, 4, 2, 65536, 8, true, true>("D  8 waves, 64 x 128 wave tiles (AGPR acc), 64 KB DMA / step, 2 stages", cus, 2000, src, mask);
+    go<8, 2, 4, 2, 65536, 8, true, false>("D  8 waves, 64 x 128 wave tiles (AGPR acc), no DMA", cus, 2000, src, mask);
   }
   hipFree(src);
   return 0;

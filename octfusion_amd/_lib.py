@@ -124,6 +124,7 @@ _SIGS = {
                                        c_p], True),
     'ofx_set_gconv_persistent': (c_i, [c_i], True),
     'ofx_set_gconv_xcd_contig': (c_i, [c_i], True),
+    'ofx_set_gconv_cus': (c_i, [c_i], True),
     'ofx_set_gemm_bn64': (c_i, [c_i], True),
     'ofx_gemm_planes_packed_bytes': (c_l, [c_i, c_i, c_i], False),
     'ofx_pack_gemm_planes': (c_i, [c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_p], True),

@@ -747,8 +747,10 @@ static int g3_launch(const Gemm3Args& A, hipStream_t st) {
   return OFX_OK;
 }
 
+static int g3_cus_override = 0;        // > 0: plan persistent launches for this many compute units (ofx_set_gconv_cus)
 static int g3_cus() {                  // compute units of the current device (cached per device)
   static int cus[OFX_MAX_DEVICES] = {};
+  if (g3_cus_override > 0) return g3_cus_override;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= OFX_MAX_DEVICES) return 0;
   if (!cus[dev]) {
@@ -795,6 +797,11 @@ static bool g3_plan(int64_t M, int cout, int nkt, int wm, int ni, G3Plan& p, int
 
 void ofx_gconv3_set_hybrid(int on) { g3_hybrid = on ? 1 : 0; }
 extern "C" int ofx_set_gconv_xcd_contig(int on) { g3_xcd_contig = on ? 1 : 0; return OFX_OK; }
+extern "C" int ofx_set_gconv_cus(int cus) {
+  if (cus < 0 || (cus > 0 && cus < 8)) return OFX_EINVAL;
+  g3_cus_override = cus;
+  return OFX_OK;
+}
 void ofx_gconv3_set_snap(int near) { g3_snap = near ? 1 : 0; }
 
 // The schedule of a persistent launch, on the host (no device work; `cus` > 0: plan for that many compute units

@@ -1,0 +1,89 @@
+"""Does the denoising step gain from running two half-batches on two HIP streams?
+
+The step is a strict chain per shape, but shapes of a batch are independent: while one half-batch sits in an MFMA-bound
+GraphConv the other could be in an HBM-bound GroupNorm / gather kernel.  This probe measures the aggregate rate of
+
+  (a) one hipGraph of the whole batch (what bench.py / sampler.sample_loop replay today), against
+  (b) two hipGraphs of half the batch each, replayed on two streams at once, the persistent GraphConv planned for
+      `--cus` compute units per launch (ofx_set_gconv_cus; 0 = all of them, i.e. both halves ask for the whole chip).
+
+usage: python tools/two_half_probe.py [--workload hr] [--batch 8] [--steps 20] [--cus 0,192,160,128]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def capture(wl, stream, i0=5):
+    """Eager warm-up on `stream` (per-stream scratch must exist before capture), then one captured step."""
+    with torch.cuda.stream(stream):
+        for i in range(3):
+            wl.step(i)
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            wl.step(i0)
+    return g
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--workload', default='hr')
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--cus', default='0,192,160,128')
+    a = ap.parse_args()
+    from octfusion_amd import _lib, ops
+    dev = torch.device('cuda:0')
+    lib = _lib.lib()
+    out = {'workload': a.workload, 'batch': a.batch, 'steps': a.steps}
+
+    def time_replays(graphs_streams):
+        def go():
+            for _ in range(a.steps):
+                for g, s in graphs_streams:
+                    with torch.cuda.stream(s):
+                        g.replay()
+            for _, s in graphs_streams:
+                s.synchronize()
+        go()
+        return min(bench.timed(go) for _ in range(3)) / a.steps * 1e3
+
+    s0 = torch.cuda.Stream(dev)
+    whole = bench.Workload(a.workload, a.batch, dev, 0)
+    g_whole = capture(whole, s0)
+    out['whole_ms'] = time_replays([(g_whole, s0)])
+    print('whole batch %d: %.3f ms/step' % (a.batch, out['whole_ms']), flush=True)
+
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    ha = bench.Workload(a.workload, a.batch // 2, dev, 0)
+    hb = bench.Workload(a.workload, a.batch // 2, dev, 0)
+    hb.net = ha.net
+    if ha.nested is not None:
+        hb.nested = ha.nested
+    out['halves'] = []
+    for cus in [int(c) for c in a.cus.split(',')]:
+        lib.ofx_set_gconv_cus(cus)
+        ga, gb = capture(ha, sa), capture(hb, sb)
+        one = time_replays([(ga, sa)])
+        two = time_replays([(ga, sa), (gb, sb)])
+        rec = {'cus': cus, 'half_alone_ms': one, 'two_halves_ms': two, 'vs_whole': two / out['whole_ms']}
+        out['halves'].append(rec)
+        print(json.dumps(rec), flush=True)
+        del ga, gb
+    lib.ofx_set_gconv_cus(0)
+    assert not ops.sync_error(dev)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -88,7 +88,7 @@ def build_tree(kind, batch, dev):
 class Workload:
     """One denoising step of a stage, driven exactly like sampler.sample_loop drives it."""
 
-    def __init__(self, name, batch, dev, rank):
+    def __init__(self, name, batch, dev, rank, lanes=None):
         from octfusion_amd import configs, dist, sampler, synthetic
         from octfusion_amd.graph_unet_union import UNet3DModel
         w = WORKLOADS[name]
@@ -121,8 +121,46 @@ class Workload:
         self.sign = [bool(t < trunc) and self.stage == 'lr' for t, _ in times]
         self.x_self = None
         self.sampler = sampler
+        # graph stages run as sampler.sample_loop runs them: LANES runs of consecutive shapes, each on its own HIP stream
+        self.lanes, self.serial, self.lane_split_ms = [], False, 0.0
+        self.n_lanes = sampler.lane_count(batch, self.doc, True) if lanes is None else int(lanes)
+        if self.doc is not None and self.n_lanes > 1:
+            self.make_lanes()
 
     RESET_EVERY = 50
+
+    def make_lanes(self):
+        """Split self.doc into the lanes of sampler.sample_loop (DualOctree.split_batch): per lane its doctree, its rows of
+        x, its labels and its stream."""
+        import types
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        parts = self.doc.split_batch(self.n_lanes)
+        torch.cuda.synchronize()
+        self.lane_split_ms = 1e3 * (time.perf_counter() - t0)
+        self.lanes = []
+        for (sub, rows, (b0, b1)), s in zip(parts, self.sampler.lane_streams(self.dev, len(parts))):
+            L = types.SimpleNamespace(doc=sub, rows=rows, batch=b1 - b0, stream=s, x=self.x_init.index_select(0, rows),
+                                      label=None if self.label is None else self.label[b0:b1].contiguous())
+            L.x_init = L.x.clone()
+            self.lanes.append(L)
+        torch.cuda.synchronize()
+
+    def set_doc(self, doc):
+        self.doc = doc
+        if self.lanes:
+            self.make_lanes()
+
+    def lane_order(self):
+        """(lane, stream to wait for first or None): lanes overlap freely (the timed region) unless self.serial, where
+        every lane's step starts after the previous lane's has finished (per-launch event timings: a kernel alone on the chip)."""
+        prev = self.lanes[-1] if self.serial else None
+        for L in self.lanes:
+            yield L, (prev.stream if prev is not None and prev is not L else None)
+            prev = L if self.serial else None
+
+    def finite(self):
+        return all(bool(torch.isfinite(L.x).all()) for L in self.lanes) if self.lanes else bool(torch.isfinite(self.x).all())
 
     def reset_input(self, i):
         """With random weights the DDIM update is not a denoiser: |x| grows a few per cent per step (hr_cond: x 1.065),
@@ -135,6 +173,18 @@ class Workload:
                 self.x_self = None
 
     def step(self, i):
+        if self.lanes:
+            j = i % 200
+            for L, after in self.lane_order():
+                if after is not None:
+                    L.stream.wait_stream(after)
+                with torch.cuda.stream(L.stream):
+                    if i % self.RESET_EVERY == 0 and i > 0:
+                        L.x.copy_(L.x_init)
+                    noise = torch.randn_like(L.x) if self.df == 'x0' and float(self.coef_host[j, 3]) != 0.0 else None
+                    self.sampler._step(self.net, L.x, self.cond[j].expand(L.batch).contiguous(), self.stage, self.df, L.doc,
+                                       self.nested, L.label, None, self.coef[j], noise, False, None)
+            return
         self.reset_input(i)
         i = i % 200
         noise = None
@@ -148,6 +198,38 @@ class Workload:
     def run(self, first, n):
         for i in range(first, first + n):
             self.step(i)
+
+
+def capture_lanes(wl):
+    """One hipGraph per lane, captured on the lane's stream after two eager steps on it (its per-stream scratch exists then)."""
+    for L in wl.lanes:
+        L.cond_s = wl.cond[0].expand(L.batch).contiguous().clone()
+        L.coef_s = wl.coef[0].clone()
+        L.noise_s = torch.randn_like(L.x) if wl.df == 'x0' else None
+
+        def lstep(L=L):
+            return wl.sampler._step(wl.net, L.x, L.cond_s, wl.stage, wl.df, L.doc, wl.nested, L.label, None,
+                                    L.coef_s, L.noise_s, False, None)
+        with torch.cuda.stream(L.stream):
+            lstep()
+            lstep()
+            L.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(L.graph, stream=L.stream):
+                lstep()
+
+
+def replay_lanes(wl, first, n):
+    for i in range(first, first + n):
+        j = i % 200
+        for L in wl.lanes:
+            with torch.cuda.stream(L.stream):
+                if i % wl.RESET_EVERY == 0 and i > 0:
+                    L.x.copy_(L.x_init)
+                L.cond_s.copy_(wl.cond[j].expand(L.batch))
+                L.coef_s.copy_(wl.coef[j])
+                if L.noise_s is not None:
+                    L.noise_s.normal_()
+                L.graph.replay()
 
 
 def timed(fn, n_sync=True):
@@ -516,6 +598,8 @@ def main():
     ap.add_argument('--precision', default='fp16x3', choices=['fp16x3', 'bf16x3', 'fp32', 'fp16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='time eager launches instead of hipGraph replay')
+    ap.add_argument('--lanes', type=int, default=None, help='lanes of a graph stage (default: sampler.lane_count; 1 = one stream)')
+    ap.add_argument('--lane-cus', type=int, default=None, help='compute units a persistent launch of a lane is planned for')
     ap.add_argument('--no-extras', action='store_true', help='skip the fp32 / old-kernel / graph / sustained side runs')
     ap.add_argument('--layers', action='store_true', help='add the per-layer table of the fused GraphConv launches')
     ap.add_argument('--bootstrap-only', action='store_true',
@@ -584,16 +668,18 @@ def main():
     W = args.warmup
     ops.set_precision(args.precision)
 
-    wl = Workload(args.workload, batch, dev, rank)
+    wl = Workload(args.workload, batch, dev, rank, lanes=args.lanes)
+    if wl.lanes:
+        ops.set_lane_cus(wl.sampler.LANE_CUS if args.lane_cus is None else args.lane_cus)
     first_ms = 1e3 * timed(lambda: wl.run(0, 1))        # first step of the process: weight packing + per-doctree tables
     new_tree_first_ms = None
     if wl.doc is not None and rank == 0:
         # what every LATER batch of shapes pays on its first step: a new doctree (its lazily built tables and operand
         # slabs) with the weights already packed
-        doc_keep = wl.doc
-        wl.doc = build_tree(w['tree'], batch, dev)[1]
+        doc_keep, lanes_keep = wl.doc, wl.lanes
+        wl.set_doc(build_tree(w['tree'], batch, dev)[1])
         new_tree_first_ms = 1e3 * timed(lambda: wl.run(0, 1))
-        wl.doc = doc_keep
+        wl.doc, wl.lanes = doc_keep, lanes_keep
     wl.run(1, max(W - 1, 0))
     torch.cuda.synchronize()
     steady_ms = 1e3 * timed(lambda: wl.run(W, 1))
@@ -627,9 +713,14 @@ def main():
                 with torch.cuda.graph(gph, stream=side_s):      # the warm-up stream: its scratch exists already (ops._no_capture)
                     out = gstep()
                 return gph, out
-            graphs = {sign: capture(sign) for sign in sorted(set(wl.sign if is_lr else [False]))}
+            if wl.lanes:
+                capture_lanes(wl)
+            else:
+                graphs = {sign: capture(sign) for sign in sorted(set(wl.sign if is_lr else [False]))}
 
             def replay(first, n):
+                if wl.lanes:
+                    return replay_lanes(wl, first, n)
                 for i in range(first, first + n):
                     if i % wl.RESET_EVERY == 0 and i > 0:
                         wl.x.copy_(wl.x_init)
@@ -674,19 +765,24 @@ def main():
     if replay is not None:
         # HIP events cannot be recorded inside a graph replay: the per-launch timings of the roofline come from an
         # eager re-run of the same K steps right after the timed region (same kernels, same inputs)
+        # (lanes: one after another in this pass, so that an event pair brackets a kernel that has the chip to itself)
+        wl.serial = True
         ops.GRAPHCONV_PROFILE = prof
         dt_prof = timed(lambda: wl.run(W + 1, K))
         ops.GRAPHCONV_PROFILE = None
+        wl.serial = False
         eager_ms = 1e3 * dt_prof / K
     # per-class accounting of everything that is not the fused GraphConv: a second eager pass with an event pair
     # around every entry-point call (kept apart from the pass above so that its brackets stay undisturbed)
     tail, n_tail = [], max(2, min(K, 5))
     if rank == 0 and not args.no_extras:
+        wl.serial = True
         _lib.PROFILE = tail
         dt_tail = timed(lambda: wl.run(W + 1, n_tail))
         _lib.PROFILE = None
+        wl.serial = False
 
-    assert bool(torch.isfinite(wl.x).all())
+    assert wl.finite()
     ops.raise_on_sync_error(dev)            # a flag wait of the persistent launch gave up: the timing would be void
 
     res = None
@@ -757,6 +853,12 @@ def main():
                                                 'build is %s: not reported' % (pj.get('kernel_source_sha16'), kernel_source_hash()))
                 except Exception as e:      # noqa: BLE001
                     roof['traffic_note'] = 'pmc_traffic.json unreadable: %s' % e
+            if wl.lanes:
+                # what the overlap is worth, in the kernel's own unit: the GraphConv flops of a step over the WHOLE step time
+                fl = dom['algorithmic_flops_per_launch'] * dom['launches'] / K / 1e9          # GFLOP per step (TFLOP/s x ms)
+                roof['whole_step'] = {'graphconv_GFLOP_per_step': fl, 'TFLOPs_over_the_timed_step': fl / ms_step,
+                                      'frac_of_matrix_peak': fl / ms_step / peak,
+                                      'same_over_the_serial_eager_step': fl / eager_ms / peak if eager_ms else None}
             roof['note'] = ('per launch, HIP events on the launching stream '
                             + ('in an eager re-run of the same K steps right after the hipGraph-replayed timed region '
                                if replay is not None else 'inside the timed region ')
@@ -784,7 +886,16 @@ def main():
                       'bf16x3': 'f32 storage, bf16x3 products (16-bit significand pairs, fp32 accumulate)',
                       'fp32': 'f32', 'fp16': 'f32 storage, fp16 products in GraphConv (reduced precision)'}[bf],
             'contraction': bf, 'data': 'synthetic',
-            'execution': 'hipGraph replay of the captured step' if replay is not None else 'eager launches',
+            'execution': ('hipGraph replay of the captured step' if replay is not None else 'eager launches')
+                         + (': %d lanes (runs of %s shapes) on %d HIP streams, one hipGraph per lane (sampler.sample_loop\'s default for '
+                            'graph stages)' % (len(wl.lanes), '/'.join(str(L.batch) for L in wl.lanes), len(wl.lanes)) if wl.lanes else ''),
+            'lanes': {'n': len(wl.lanes), 'shapes': [L.batch for L in wl.lanes], 'rows': [int(L.x.shape[0]) for L in wl.lanes],
+                      'persistent_launch_planned_for_cus': (wl.sampler.LANE_CUS if args.lane_cus is None else args.lane_cus) or 'all',
+                      'split_ms_per_batch_of_shapes': wl.lane_split_ms,
+                      'note': 'the shapes of a batch share nothing in the net, so a stage runs as independent half-batches whose '
+                              'matrix-bound and HBM-bound launches overlap; `roofline` and `roofline_tail` are per-launch event '
+                              'timings of an eager pass with the lanes one after another (a kernel alone on the chip, at the '
+                              'lane\'s row count); --lanes 1 runs the whole batch on one stream'} if wl.lanes else None,
             'eager_ms_per_step': eager_ms if replay is not None else ms_step,
             'config': {'workload': w['desc'] % batch, 'name': args.workload, 'config': w['config'],
                        'batch_per_gpu': batch, 'nodes_per_gpu': wl.doc.total_num if wl.doc else None,
@@ -859,6 +970,26 @@ def main():
             ops.USE_PLANES = True
             _lib.call('ofx_set_gconv_persistent', 1)
         res['side_runs'] = extras
+        if wl.doc is not None and not wl.lanes and batch >= 2 and replay is not None:
+            # in-run A/B of sampler.sample_loop's opt-in lanes (OFX_LANES=2): the same step as two half-batches on two HIP
+            # streams, one hipGraph each, the persistent launches planned for LANE_CUS compute units
+            try:
+                base = 1e3 * timed(lambda: run_timed(0, n_side)) / n_side
+                wl.n_lanes = 2
+                ops.set_lane_cus(wl.sampler.LANE_CUS)
+                wl.make_lanes()
+                wl.run(0, 2)
+                capture_lanes(wl)
+                replay_lanes(wl, 0, 2)
+                two = 1e3 * timed(lambda: replay_lanes(wl, 2, n_side)) / n_side
+                res['lanes_ab'] = {'one_lane_ms_per_step': base, 'two_lanes_ms_per_step': two, 'steps': n_side,
+                                   'planned_for_cus': wl.sampler.LANE_CUS, 'finite': wl.finite(),
+                                   'note': 'hipGraph replay both; off by default (octfusion_amd/sampler.py: LANES)'}
+            except Exception as e:      # noqa: BLE001
+                res['lanes_ab'] = {'error': str(e)}
+            finally:
+                ops.set_lane_cus(0)
+                wl.lanes, wl.n_lanes = [], 1
         if 'fp16_single_pass' in extras:
             # BASELINE configs[4] names "fp16 MFMA": the single-pass fp16 contraction as a peer of `value` (eager launches).
             # It is NOT the shipped default: element-wise p99.9 2e-2 against the fp64 oracle (whole-step rel-to-max 4.5e-4,

@@ -523,8 +523,10 @@ int ofx_set_gemm_bn64(int max_n);
 /* A/B knob of the persistent launch's tile order: 1 = every XCD walks one contiguous range of tiles over the whole
  * launch (csrc/ofx_gemm3.hip, Gemm3Args::xcd_contig), 0 = the XCDs interleave inside every whole-tile round. */
 int ofx_set_gconv_xcd_contig(int on);
-/* Probe knob (tools/two_half_probe.py): plan the persistent launches for `cus` compute units instead of the device's
- * (0 = the device's), so that two launches on two streams can be resident side by side.  OFX_EINVAL for 1..7. */
+/* Plan the persistent launches for at most `cus` compute units (0 = all of the device's; values above the device's
+ * count are clamped to it), so that the launches of two lanes on two HIP streams can be resident side by side
+ * (octfusion_amd/sampler.py: lanes; tools/two_half_probe.py).  Process-wide; affects launches issued or captured
+ * afterwards.  OFX_EINVAL for 1..7. */
 int ofx_set_gconv_cus(int cus);
 /* The schedule ofx_graphconv_fwd_planes' persistent launch would use for n_rows x cout outputs and nkt k-steps per tile
  * (host only, no device work; cus > 0: plan for that many compute units): out[0..4] = blocks G, q, rem, region units U,

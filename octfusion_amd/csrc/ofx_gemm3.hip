@@ -747,10 +747,9 @@ static int g3_launch(const Gemm3Args& A, hipStream_t st) {
   return OFX_OK;
 }
 
-static int g3_cus_override = 0;        // > 0: plan persistent launches for this many compute units (ofx_set_gconv_cus)
+static int g3_cus_override = 0;        // > 0: plan persistent launches for at most this many compute units (ofx_set_gconv_cus)
 static int g3_cus() {                  // compute units of the current device (cached per device)
   static int cus[OFX_MAX_DEVICES] = {};
-  if (g3_cus_override > 0) return g3_cus_override;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= OFX_MAX_DEVICES) return 0;
   if (!cus[dev]) {
@@ -758,7 +757,8 @@ static int g3_cus() {                  // compute units of the current device (c
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     cus[dev] = n;
   }
-  return cus[dev];
+  // never MORE blocks than the device can keep resident: the hand-off waits rely on it
+  return g3_cus_override > 0 && g3_cus_override < cus[dev] ? g3_cus_override : cus[dev];
 }
 
 // Bytes of workspace the persistent launch needs behind the statistics partials (0: the shape is not eligible).

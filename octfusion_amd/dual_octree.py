@@ -199,6 +199,27 @@ class DualOctree:
     def batch_id(self, depth, nempty=False):
         return self.batch_id_dict[depth]
 
+    def split_batch(self, parts):
+        """The batch as `parts` independent dual octrees of consecutive elements: [(DualOctree, rows, (b0, b1))] with
+        `rows` the int64 indices of the part's rows among this doctree's rows at the finest graph depth (a row tensor
+        x of the whole batch is x[rows] for the part, in the part's own row order: every depth segment of the graph is
+        batch-sorted, so a part keeps the relative order).  Shapes of a batch share nothing in the network (GroupNorm
+        statistics are per element, graphs never cross elements), so a step over the whole batch equals the steps over
+        the parts; sampler.sample_loop runs them as lanes on separate HIP streams."""
+        B = self.batch_size
+        parts = max(1, min(int(parts), B))
+        bounds = [B * p // parts for p in range(parts + 1)]
+        bid = self.batch_id(self.depth)
+        out = []
+        for oc, b0, b1 in zip(self.octree.batch_slices(bounds), bounds, bounds[1:]):
+            rows = torch.nonzero((bid >= b0) & (bid < b1)).squeeze(1)
+            sub = DualOctree(oc)
+            if sub.total_num != rows.numel():
+                raise _lib.OfxError('split_batch: part %d..%d has %d graph rows, the batch holds %d of them'
+                                    % (b0, b1, sub.total_num, rows.numel()))
+            out.append((sub, rows, (b0, b1)))
+        return out
+
     def node_child(self, depth):
         s = int(self.ncum[depth])
         return self.child[s: s + int(self.nnum[depth])]

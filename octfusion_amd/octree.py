@@ -160,6 +160,44 @@ class Octree:
     def cuda(self):
         return self
 
+    def batch_slices(self, bounds):
+        """Sub-octrees of consecutive batch ranges [bounds[i], bounds[i+1]): the inverse of merge_octrees for runs of
+        elements.  Nodes of a depth are sorted by key with the batch id on top (bits 48..), so every element range is
+        one contiguous run per depth: keys lose the range's first batch id, child pointers the non-empty nodes in front
+        of the run.  Index plumbing on the per-depth arrays; two host reads for all ranges together (run bounds, then
+        non-empty counts -- they size the sub-octrees' host tables).  Used by sampler.sample_loop to run a batch as
+        independent lanes on separate HIP streams."""
+        bounds = [int(b) for b in bounds]
+        if bounds[0] < 0 or bounds[-1] > self.batch_size or any(a >= b for a, b in zip(bounds, bounds[1:])):
+            raise ValueError('batch_slices: bounds %r for batch size %d' % (bounds, self.batch_size))
+        nd = self.depth + 1
+        edges = torch.tensor(bounds, dtype=torch.int64, device=self.device) << 48
+        cut = torch.stack([torch.searchsorted(self.keys[d], edges) for d in range(nd)]).tolist()     # host read 1
+        csum = [torch.cumsum((self.children[d] >= 0).to(torch.int64), 0) for d in range(nd)]
+        zero = torch.zeros(1, dtype=torch.int64, device=self.device)
+        before = torch.stack([torch.cat([zero, csum[d]])[torch.tensor(cut[d], device=self.device)]
+                              for d in range(nd)]).tolist()                                           # host read 2
+        out = []
+        for i, (b0, b1) in enumerate(zip(bounds, bounds[1:])):
+            oc = Octree(self.depth, self.full_depth, b1 - b0, self.device)
+            oc.keys, oc.children = [None] * nd, [None] * nd
+            oc.nnum, oc.nnum_nempty = torch.zeros(nd, dtype=torch.int64), torch.zeros(nd, dtype=torch.int64)
+            for d in range(nd):
+                lo, hi = cut[d][i], cut[d][i + 1]
+                oc.keys[d] = self.keys[d][lo:hi] - (b0 << 48)
+                c = self.children[d][lo:hi]
+                off = before[d][i]
+                oc.children[d] = torch.where(c >= 0, c - off, c) if off else c.clone()
+                oc.nnum[d] = hi - lo
+                oc.nnum_nempty[d] = before[d][i + 1] - off
+            feat = getattr(self, '_feature_nd', None)
+            if feat is not None:
+                lo, hi = cut[self.depth][i], cut[self.depth][i + 1]
+                oc._feature_nd = feat[lo:hi]
+                oc._avg_points = self._avg_points[lo:hi]
+            out.append(oc)
+        return out
+
 
 class Points:
     """ocnn.octree.Points as the reference uses it (datasets/dualoctree_snet.py:39-47): positions in [-1, 1],

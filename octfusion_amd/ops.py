@@ -266,6 +266,12 @@ SIDE_STREAM = os.environ.get('OFX_SIDE_STREAM', '0') == '1'
 _SIDE = {}
 
 
+def set_lane_cus(cus):
+    """Compute units a persistent GraphConv launch is planned for while sampler.sample_loop runs a stage as lanes
+    (ofx_set_gconv_cus, include/ofx.h); 0 = the whole device."""
+    call('ofx_set_gconv_cus', int(cus))
+
+
 def side_stream(device):
     """The per-device side stream for work that is independent of the main chain (joined before its result is used)."""
     s = _SIDE.get(device.index)
@@ -1080,8 +1086,7 @@ def group_norm(x, batch_id, count, batch_size, weight, bias, groups, eps=1e-5, a
         sums = stats
     else:
         _meta('gn_stats', 0, 4.0 * n * C, (n, C))
-        p = _stats_pool
-        if p.depth > 0 and p.buf.device == dev and p.cur + batch_size * C * 2 <= p.SIZE:
+        if stats_pool_has_room(batch_size * C * 2, dev):
             sums = stats_zeros(batch_size * C * 2, dev)          # pre-zeroed pool slice: no memset node in the step
             call('ofx_gn_stats_acc', ptr(x), ldx, n, C, ptr(batch_id), batch_size, ptr(sums), stream())
         else:
@@ -1182,7 +1187,9 @@ STATS_ATTR = '_ofx_gn_stats'
 
 class _StatsPool:
     """Zero-initialised fp64 slices for the fused GroupNorm statistics: one fill per network forward instead
-    of one per GraphConv (each tiny fill costs a full launch slot on the stream)."""
+    of one per GraphConv (each tiny fill costs a full launch slot on the stream).  One pool per (device, STREAM), like
+    the other scratch: forwards on different streams (the lanes of sampler.sample_loop, graphs captured on their own
+    stream) run concurrently and must not zero or accumulate into each other's slices."""
     SIZE = 1 << 19                      # doubles (4 MB)
 
     def __init__(self):
@@ -1192,16 +1199,25 @@ class _StatsPool:
         self.gen = 0
 
 
-_stats_pool = _StatsPool()
+_stats_pools = {}
+
+
+def _stats_pool_of(device):
+    key = (device.type, device.index, _stream_id(device))
+    p = _stats_pools.get(key)
+    if p is None:
+        p = _stats_pools[key] = _StatsPool()
+    return p
 
 
 @contextlib.contextmanager
 def stats_scope(device):
     """Buffers handed out by stats_zeros() inside the (outermost) scope come from one pre-zeroed pool; they are
-    valid until the next outermost scope begins (get_stats() drops stale ones)."""
-    p = _stats_pool
+    valid until the next outermost scope on the same stream begins (get_stats() drops stale ones)."""
+    p = _stats_pool_of(device)
     if p.depth == 0:
-        if p.buf is None or p.buf.device != device:
+        if p.buf is None:
+            _no_capture('the GroupNorm statistics pool')
             p.buf = torch.empty(p.SIZE, dtype=torch.float64, device=device)
         p.buf.zero_()
         p.cur = 0
@@ -1213,12 +1229,18 @@ def stats_scope(device):
         p.depth -= 1
 
 
+def stats_pool_has_room(n, device):
+    p = _stats_pool_of(device)
+    return p.depth > 0 and p.cur + n <= p.SIZE
+
+
 def stats_zeros(n, device):
-    p = _stats_pool
-    if p.depth > 0 and p.buf.device == device and p.cur + n <= p.SIZE:
+    p = _stats_pool_of(device)
+    if p.depth > 0 and p.cur + n <= p.SIZE:
         st = p.buf[p.cur:p.cur + n]
         p.cur += (n + 1) & ~1           # keep 16-B alignment
         st._ofx_gen = p.gen
+        st._ofx_pool = p
         return st
     return torch.zeros(n, dtype=torch.float64, device=device)
 
@@ -1226,7 +1248,8 @@ def stats_zeros(n, device):
 def get_stats(t):
     """GroupNorm sums attached to a tensor by the kernel epilogue that produced it (or None)."""
     st = getattr(t, STATS_ATTR, None)
-    if st is not None and getattr(st, '_ofx_gen', _stats_pool.gen) != _stats_pool.gen:
+    pool = getattr(st, '_ofx_pool', None)
+    if pool is not None and st._ofx_gen != pool.gen:
         return None                     # pooled slice from an earlier forward: recycled since
     return st
 

@@ -41,6 +41,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--cus', default='0,192,160,128')
+    ap.add_argument('--parts', default='2')
     a = ap.parse_args()
     from octfusion_amd import _lib, ops
     dev = torch.device('cuda:0')
@@ -59,27 +60,31 @@ def main():
         return min(bench.timed(go) for _ in range(3)) / a.steps * 1e3
 
     s0 = torch.cuda.Stream(dev)
-    whole = bench.Workload(a.workload, a.batch, dev, 0)
+    whole = bench.Workload(a.workload, a.batch, dev, 0, lanes=1)
     g_whole = capture(whole, s0)
     out['whole_ms'] = time_replays([(g_whole, s0)])
     print('whole batch %d: %.3f ms/step' % (a.batch, out['whole_ms']), flush=True)
 
-    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    ha = bench.Workload(a.workload, a.batch // 2, dev, 0)
-    hb = bench.Workload(a.workload, a.batch // 2, dev, 0)
-    hb.net = ha.net
-    if ha.nested is not None:
-        hb.nested = ha.nested
     out['halves'] = []
-    for cus in [int(c) for c in a.cus.split(',')]:
-        lib.ofx_set_gconv_cus(cus)
-        ga, gb = capture(ha, sa), capture(hb, sb)
-        one = time_replays([(ga, sa)])
-        two = time_replays([(ga, sa), (gb, sb)])
-        rec = {'cus': cus, 'half_alone_ms': one, 'two_halves_ms': two, 'vs_whole': two / out['whole_ms']}
-        out['halves'].append(rec)
-        print(json.dumps(rec), flush=True)
-        del ga, gb
+    for parts in [int(c) for c in a.parts.split(',')]:
+        if a.batch % parts:
+            continue
+        streams = [torch.cuda.Stream(dev) for _ in range(parts)]
+        wls = [bench.Workload(a.workload, a.batch // parts, dev, 0, lanes=1) for _ in range(parts)]
+        for w in wls[1:]:
+            w.net = wls[0].net
+            if wls[0].nested is not None:
+                w.nested = wls[0].nested
+        for cus in [int(c) for c in a.cus.split(',')]:
+            lib.ofx_set_gconv_cus(cus)
+            gs = [capture(w, s) for w, s in zip(wls, streams)]
+            one = time_replays([(gs[0], streams[0])])
+            allp = time_replays(list(zip(gs, streams)))
+            rec = {'parts': parts, 'cus': cus, 'part_alone_ms': one, 'all_parts_ms': allp, 'vs_whole': allp / out['whole_ms']}
+            out['halves'].append(rec)
+            print(json.dumps(rec), flush=True)
+            del gs
+        del wls
     lib.ofx_set_gconv_cus(0)
     assert not ops.sync_error(dev)
     print(json.dumps(out))

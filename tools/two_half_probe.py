@@ -7,6 +7,11 @@ GraphConv the other could be in an HBM-bound GroupNorm / gather kernel.  This pr
   (b) two hipGraphs of half the batch each, replayed on two streams at once, the persistent GraphConv planned for
       `--cus` compute units per launch (ofx_set_gconv_cus; 0 = all of them, i.e. both halves ask for the whole chip).
 
+History: the first run of this probe (profiles/r06/two_half_*.txt) showed -12 ... -16 %.  That was a data race on the
+then process-wide GroupNorm statistics pool (now per stream): the lanes' activations went non-finite and the launches ran
+faster on NaN operands.  The probe now checks that every lane's state is finite; on correct data the gain is 2-5 %
+(profiles/r06/lanes_ab.txt, bench.py --lanes 2).
+
 usage: python tools/two_half_probe.py [--workload hr] [--batch 8] [--steps 20] [--cus 0,192,160,128]
 """
 import argparse
@@ -80,7 +85,8 @@ def main():
             gs = [capture(w, s) for w, s in zip(wls, streams)]
             one = time_replays([(gs[0], streams[0])])
             allp = time_replays(list(zip(gs, streams)))
-            rec = {'parts': parts, 'cus': cus, 'part_alone_ms': one, 'all_parts_ms': allp, 'vs_whole': allp / out['whole_ms']}
+            rec = {'parts': parts, 'cus': cus, 'part_alone_ms': one, 'all_parts_ms': allp, 'vs_whole': allp / out['whole_ms'],
+                   'finite': all(w.finite() for w in wls)}
             out['halves'].append(rec)
             print(json.dumps(rec), flush=True)
             del gs

@@ -930,6 +930,27 @@ def main():
                             'mode': 'hipGraph replay' if replay is not None else 'eager'}
         res['hipgraph_replay_ms_per_step'] = ms_step if replay is not None else None
         n_side = max(5, min(K, 20))
+        if wl.doc is not None and not wl.lanes and batch >= 2 and replay is not None:
+            # (before the side runs, like the sustained run: they re-pack the weights the captured graphs point at)
+            # in-run A/B of sampler.sample_loop's opt-in lanes (OFX_LANES=2): the same step as two half-batches on two HIP
+            # streams, one hipGraph each, the persistent launches planned for LANE_CUS compute units
+            try:
+                base = 1e3 * timed(lambda: run_timed(0, n_side)) / n_side
+                wl.n_lanes = 2
+                ops.set_lane_cus(wl.sampler.LANE_CUS)
+                wl.make_lanes()
+                wl.run(0, 2)
+                capture_lanes(wl)
+                replay_lanes(wl, 0, 2)
+                two = 1e3 * timed(lambda: replay_lanes(wl, 2, n_side)) / n_side
+                res['lanes_ab'] = {'one_lane_ms_per_step': base, 'two_lanes_ms_per_step': two, 'steps': n_side,
+                                   'planned_for_cus': wl.sampler.LANE_CUS, 'finite': wl.finite(),
+                                   'note': 'hipGraph replay both; off by default (octfusion_amd/sampler.py: LANES)'}
+            except Exception as e:      # noqa: BLE001
+                res['lanes_ab'] = {'error': str(e)}
+            finally:
+                ops.set_lane_cus(0)
+                wl.lanes, wl.n_lanes = [], 1
         extras = {}
 
         def side(label, precision, planes, persistent=1):
@@ -970,26 +991,6 @@ def main():
             ops.USE_PLANES = True
             _lib.call('ofx_set_gconv_persistent', 1)
         res['side_runs'] = extras
-        if wl.doc is not None and not wl.lanes and batch >= 2 and replay is not None:
-            # in-run A/B of sampler.sample_loop's opt-in lanes (OFX_LANES=2): the same step as two half-batches on two HIP
-            # streams, one hipGraph each, the persistent launches planned for LANE_CUS compute units
-            try:
-                base = 1e3 * timed(lambda: run_timed(0, n_side)) / n_side
-                wl.n_lanes = 2
-                ops.set_lane_cus(wl.sampler.LANE_CUS)
-                wl.make_lanes()
-                wl.run(0, 2)
-                capture_lanes(wl)
-                replay_lanes(wl, 0, 2)
-                two = 1e3 * timed(lambda: replay_lanes(wl, 2, n_side)) / n_side
-                res['lanes_ab'] = {'one_lane_ms_per_step': base, 'two_lanes_ms_per_step': two, 'steps': n_side,
-                                   'planned_for_cus': wl.sampler.LANE_CUS, 'finite': wl.finite(),
-                                   'note': 'hipGraph replay both; off by default (octfusion_amd/sampler.py: LANES)'}
-            except Exception as e:      # noqa: BLE001
-                res['lanes_ab'] = {'error': str(e)}
-            finally:
-                ops.set_lane_cus(0)
-                wl.lanes, wl.n_lanes = [], 1
         if 'fp16_single_pass' in extras:
             # BASELINE configs[4] names "fp16 MFMA": the single-pass fp16 contraction as a peer of `value` (eager launches).
             # It is NOT the shipped default: element-wise p99.9 2e-2 against the fp64 oracle (whole-step rel-to-max 4.5e-4,

@@ -164,3 +164,73 @@ def test_whole_box_cpu_workers_orchestration(monkeypatch):
     assert wb['processes'] == min(8, usable // 4) and wb['threads_per_process'] == 4 and wb['value'] > 0
     assert len(wb['timed_s_per_worker']) == wb['processes'] and wb['common_window_s'] > 0
     assert r['value'] >= max(r['single_process']['value'], 0) * 0.999 or r['value'] == wb['value']
+
+
+def _cpu_octree(depth, fd, seed):
+    """A one-element octree on CPU tensors with random splits below the full layer (only the arrays batch_slices /
+    merge_octrees touch: keys, children, nnum, nnum_nempty)."""
+    from octfusion_amd.octree import Octree
+    g = torch.Generator().manual_seed(seed)
+    oc = Octree.__new__(Octree)
+    oc.depth, oc.full_depth, oc.batch_size, oc.device = depth, fd, 1, torch.device('cpu')
+    oc.keys, oc.children = [], []
+    oc.nnum, oc.nnum_nempty = torch.zeros(depth + 1, dtype=torch.int64), torch.zeros(depth + 1, dtype=torch.int64)
+    keys = torch.zeros(1, dtype=torch.int64)
+    for d in range(depth + 1):
+        if d > 0:
+            parents = oc.keys[d - 1][oc.children[d - 1] >= 0]
+            keys = (parents[:, None] * 8 + torch.arange(8)[None, :]).reshape(-1)
+        split = torch.ones(keys.numel(), dtype=torch.bool) if d < fd else torch.rand(keys.numel(), generator=g) < 0.4
+        if d == depth:
+            split[:] = False
+        child = torch.full((keys.numel(),), -1, dtype=torch.int32)
+        child[split] = torch.arange(int(split.sum()), dtype=torch.int32)
+        oc.keys.append(keys)
+        oc.children.append(child)
+        oc.nnum[d], oc.nnum_nempty[d] = keys.numel(), int(split.sum())
+    return oc
+
+
+def test_batch_slices_inverts_merge_octrees(monkeypatch):
+    """Octree.batch_slices (the lanes of sampler.sample_loop) on CPU tensors: slicing the merge of four one-element octrees
+    gives back the elements / the merges of runs of them, keys, child pointers and counts."""
+    from octfusion_amd import _lib
+    from octfusion_amd.octree import merge_octrees
+    monkeypatch.setattr(_lib, 'require_device', lambda: None)
+    elems = [_cpu_octree(4, 1, s) for s in (3, 4, 5, 6)]
+    elems[2] = _cpu_octree(4, 1, 99)
+    elems[2].children[1][:] = -1                     # an element with nothing below the full layer
+    elems[2].nnum_nempty[1] = 0
+    for d in (2, 3, 4):
+        elems[2].keys[d], elems[2].children[d] = elems[2].keys[d][:0], elems[2].children[d][:0]
+        elems[2].nnum[d] = elems[2].nnum_nempty[d] = 0
+    whole = merge_octrees(elems)
+    for bounds in ([0, 1, 2, 3, 4], [0, 2, 4], [0, 3, 4], [1, 3]):
+        got = whole.batch_slices(bounds)
+        assert len(got) == len(bounds) - 1
+        for oc, b0, b1 in zip(got, bounds, bounds[1:]):
+            want = merge_octrees(elems[b0:b1])
+            assert oc.batch_size == b1 - b0
+            assert torch.equal(oc.nnum, want.nnum) and torch.equal(oc.nnum_nempty, want.nnum_nempty)
+            for d in range(5):
+                assert torch.equal(oc.keys[d], want.keys[d]) and torch.equal(oc.children[d], want.children[d]), (bounds, b0, d)
+    import pytest
+    with pytest.raises(ValueError):
+        whole.batch_slices([0, 5])
+    with pytest.raises(ValueError):
+        whole.batch_slices([2, 2])
+
+
+def test_lane_count_rules(monkeypatch):
+    from octfusion_amd import sampler
+    doc = types.SimpleNamespace(split_batch=lambda n: None)
+    monkeypatch.setattr(sampler, 'LANES', 1)
+    assert sampler.lane_count(8, doc, True) == 1                      # the default: one stream
+    monkeypatch.setattr(sampler, 'LANES', 2)
+    assert sampler.lane_count(8, doc, True) == 2
+    assert sampler.lane_count(8, doc, False) == 1                     # eager launches are host-bound: nothing to overlap
+    assert sampler.lane_count(8, None, True) == 1                     # the dense lr stage
+    assert sampler.lane_count(1, doc, True) == 1                      # one shape cannot be split
+    assert sampler.lane_count(8, object(), True) == 1                 # a doctree that cannot split itself
+    monkeypatch.setattr(sampler, 'LANES', 4)
+    assert sampler.lane_count(3, doc, True) == 3

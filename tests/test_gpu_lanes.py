@@ -157,3 +157,24 @@ def test_graphconv_planned_for_fewer_compute_units():
         ops.set_lane_cus(0)
     assert torch.equal(conv(x, doc, d), base)
     assert not ops.sync_error(dev())
+
+
+def test_lanes_at_the_bench_size():
+    """configs[2] at its real widths, eight shapes (N6 = 217 008), two lanes of four on two streams with the persistent
+    launches planned for LANE_CUS compute units, hipGraph replay: the whole stage against the one-lane call."""
+    from octfusion_amd import configs, ops, sampler, synthetic
+    from octfusion_amd.dual_octree import DualOctree
+    from octfusion_amd.graph_unet_union import UNet3DModel
+    net = UNet3DModel(**configs.unet_params('snet_uncond', 'hr'))
+    net.load_state_dict(synthetic.random_state_dict(net))
+    net = net.to(dev()).eval()
+    doc = DualOctree(_octree(synthetic.shell6_split(8, jitter=True)))
+    shp = (doc.total_num, 3)
+    init = torch.randn(shp, generator=torch.Generator().manual_seed(3))
+    kw = dict(doctree=doc, unet_lr=net.unet_lr, init_noise=init, use_graph=True)
+    one = sampler.sample_loop(net, shp, 8, 3, 'hr', 'eps', dev(), lanes=1, **kw)
+    two = sampler.sample_loop(net, shp, 8, 3, 'hr', 'eps', dev(), lanes=2, **kw)
+    torch.cuda.synchronize()
+    assert not ops.sync_error(dev())
+    e = errors(two, one.double())
+    assert e['rel_to_max'] < 5e-5, e
